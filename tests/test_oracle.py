@@ -1,0 +1,70 @@
+"""Pins the CPU oracle (oracle/nnet_ref.c) against vectors produced by the reference itself."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from bokego_amd.bkw import load_bkw
+from oracle.oracle import OraclePolicy, OracleValue
+
+from conftest import GOLDEN
+
+TOL_LOGIT = 1e-4   # north_star tolerance (fp32, logits reach |50|)
+TOL_VALUE = 1e-4
+TOL_PROB = 1e-5
+
+
+@pytest.fixture(scope="module")
+def nets():
+    return (OraclePolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw"))),
+            OracleValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    f = np.load(os.path.join(GOLDEN, "features.npz"))["incremental"].astype(np.float32)
+    n = np.load(os.path.join(GOLDEN, "nets.npz"))
+    return f, n
+
+
+def test_known_answers_empty_board(nets, gold):
+    # SURVEY 8c known answers for policy_19 on the empty board
+    f, n = gold
+    assert f[0].sum() == 531
+    lg, pr = nets[0](f[:1], want_probs=True)
+    assert abs(lg[0, 40] - 12.709958) < 1e-4 and abs(lg.max() - 12.709958) < 1e-4
+    assert abs(lg.min() + 15.542190) < 1e-4
+    assert abs(pr[0, 40] - 0.818645) < 1e-5
+
+
+def test_policy_matches_reference(nets, gold):
+    f, n = gold
+    lg, pr = nets[0](f, want_probs=True)
+    assert np.abs(lg - n["logits_b1"]).max() < TOL_LOGIT
+    assert np.abs(pr - n["probs_b1"]).max() < TOL_PROB
+    assert np.array_equal(lg.argmax(1), n["logits_b1"].argmax(1))
+
+
+def test_value_matches_reference(nets, gold):
+    f, n = gold
+    v = nets[1](f)
+    assert np.abs(v - n["values_b1"]).max() < TOL_VALUE
+
+
+def test_layer_activations(nets):
+    L = np.load(os.path.join(GOLDEN, "layers.npz"))
+    f = np.load(os.path.join(GOLDEN, "features.npz"))["incremental"].astype(np.float32)[L["index"]]
+    _, acts = nets[0](f, want_acts=True)
+    assert np.abs(acts - L["policy"]).max() < 1e-4
+    _, vacts = nets[1](f, want_acts=True)
+    assert np.abs(vacts - L["value"]).max() < 1e-4
+    # the two trunks are different networks (catches accidental trunk sharing)
+    assert np.abs(L["policy"] - L["value"]).max() > 1e-2
+
+
+def test_playout_positions(nets):
+    p = np.load(os.path.join(GOLDEN, "playouts.npz"))
+    f = p["features"].astype(np.float32)
+    assert np.abs(nets[0](f) - p["logits"]).max() < TOL_LOGIT
+    assert np.abs(nets[1](f) - p["values"]).max() < TOL_VALUE
