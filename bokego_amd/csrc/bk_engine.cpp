@@ -1,0 +1,440 @@
+// bk_engine.cpp -- host side of libbokego_amd.so: weight folding/packing, buffers, streams, C ABI.
+//
+// Reference call sites replaced (see include/bokego_amd.h for the per-function citations):
+//   boke.py:30-38 (construct + load_state_dict + eval), mcts.py:74-76 (.to(device)),
+//   nnet.py:265-297 (policy_dist / value / policy_sample forward calls).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bokego_amd.h"
+#include "bk_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr double kBnEps = 1e-5;  // torch.nn.BatchNorm default, nnet.py:33,98-99
+
+struct Slot {  // one in-flight host-buffer request
+    int64_t ticket = 0;
+    int B = 0, want = 0;
+    float *logits = nullptr, *probs = nullptr, *values = nullptr;  // caller's host buffers
+    void* h_in = nullptr;                                          // pinned staging
+    float *h_logits = nullptr, *h_probs = nullptr, *h_values = nullptr;
+    void* d_in = nullptr;
+    float *d_logits = nullptr, *d_probs = nullptr, *d_values = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct bk_engine {
+    int device = 0;
+    int max_batch = 0;
+    int n_cu = 256;
+    bool has_policy = false, has_value = false;
+    hipStream_t stream = nullptr;
+    std::vector<void*> dev_allocs;
+    bk_net_params net[2]{};
+    Slot slots[BK_MAX_INFLIGHT];
+    int64_t next_ticket = 1;
+    std::string err;
+    // stats / profiling
+    bk_stats_t st{};
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
+    size_t ev_head = 0, ev_pending = 0;
+};
+
+namespace {
+
+int fail(bk_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIP_TRY(e, call)                                                                       \
+    do {                                                                                       \
+        hipError_t _s = (call);                                                                \
+        if (_s != hipSuccess)                                                                  \
+            return fail(e, _s == hipErrorOutOfMemory ? BK_ERR_OOM : BK_ERR_HIP,                \
+                        std::string(#call) + ": " + hipGetErrorString(_s));                    \
+    } while (0)
+
+bool trunk_ok(const bk_trunk_weights& t) {
+    for (int l = 0; l < 7; ++l)
+        if (!t.conv_w[l] || !t.conv_b[l] || !t.bn_w[l] || !t.bn_b[l] || !t.bn_mean[l] || !t.bn_var[l]) return false;
+    return t.head_w && t.head_b;
+}
+
+// Fold BatchNorm2d (eval) into conv l and emit the per-wave MFMA fragment order consumed by
+// conv_layer<> in bk_kernels.hip:
+//   index = ((w*TAPS + t)*G + g)*256 + lane*4 + j
+//   cout = 32w + (lane&31), cin = 8g + 4(lane>>5) + j, tap t = ky*K + kx
+void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
+    wfrag.assign(BK_WFRAG_FLOATS + BK_WFRAG_PAD_FLOATS, 0.f);
+    bias.assign(7 * 128, 0.f);
+    size_t base = 0;
+    for (int l = 0; l < 7; ++l) {
+        const int K = l == 0 ? 5 : 3, cin = l == 0 ? 27 : 128, G = l == 0 ? 4 : 16, TAPS = K * K;
+        std::vector<double> scale(128);
+        for (int co = 0; co < 128; ++co) {
+            scale[co] = (double)t.bn_w[l][co] / std::sqrt((double)t.bn_var[l][co] + kBnEps);
+            bias[l * 128 + co] = (float)(((double)t.conv_b[l][co] - (double)t.bn_mean[l][co]) * scale[co] + (double)t.bn_b[l][co]);
+        }
+        for (int w = 0; w < 4; ++w)
+            for (int tp = 0; tp < TAPS; ++tp)
+                for (int g = 0; g < G; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = 32 * w + (lane & 31), ci = 8 * g + 4 * (lane >> 5) + j;
+                            float v = 0.f;
+                            if (ci < cin) v = (float)((double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co]);
+                            wfrag[base + (((size_t)w * TAPS + tp) * G + g) * 256 + lane * 4 + j] = v;
+                        }
+        base += (size_t)4 * TAPS * G * 256;
+    }
+}
+
+template <typename T>
+int upload(bk_engine* e, const std::vector<T>& h, const T** out) {
+    void* d = nullptr;
+    HIP_TRY(e, hipMalloc(&d, h.size() * sizeof(T)));
+    e->dev_allocs.push_back(d);
+    HIP_TRY(e, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return BK_OK;
+}
+
+int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, double head_scale, double head_shift) {
+    std::vector<float> wfrag, bias, hw(128), hb(81);
+    pack_trunk(t, wfrag, bias);
+    // Conv2dUntiedBias (nnet.py:175-180); for the value net BatchNorm2d(1) is folded in:
+    //   bn(h) = (h - mean) * s + beta  with  s = gamma / sqrt(var + eps)
+    for (int c = 0; c < 128; ++c) hw[c] = (float)((double)t.head_w[c] * head_scale);
+    for (int q = 0; q < 81; ++q) hb[q] = (float)((double)t.head_b[q] * head_scale + head_shift);
+    int rc;
+    if ((rc = upload(e, wfrag, &np.wfrag))) return rc;
+    if ((rc = upload(e, bias, &np.bias))) return rc;
+    if ((rc = upload(e, hw, &np.head_w))) return rc;
+    if ((rc = upload(e, hb, &np.head_b))) return rc;
+    return BK_OK;
+}
+
+int alloc_slot(bk_engine* e, Slot& s) {
+    const size_t B = (size_t)e->max_batch;
+    HIP_TRY(e, hipHostMalloc(&s.h_in, B * 2187 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(e, hipMalloc(&s.d_in, B * 2187 * sizeof(float)));
+    if (e->has_policy) {
+        HIP_TRY(e, hipHostMalloc((void**)&s.h_logits, B * 81 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(e, hipHostMalloc((void**)&s.h_probs, B * 81 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(e, hipMalloc((void**)&s.d_logits, B * 81 * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&s.d_probs, B * 81 * sizeof(float)));
+    }
+    if (e->has_value) {
+        HIP_TRY(e, hipHostMalloc((void**)&s.h_values, B * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(e, hipMalloc((void**)&s.d_values, B * sizeof(float)));
+    }
+    HIP_TRY(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    return BK_OK;
+}
+
+void free_slot(Slot& s) {
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_logits) (void)hipHostFree(s.h_logits);
+    if (s.h_probs) (void)hipHostFree(s.h_probs);
+    if (s.h_values) (void)hipHostFree(s.h_values);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_logits) (void)hipFree(s.d_logits);
+    if (s.d_probs) (void)hipFree(s.d_probs);
+    if (s.d_values) (void)hipFree(s.d_values);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s = Slot{};
+}
+
+int check_want(bk_engine* e, int B, int want) {
+    if (!e) return BK_ERR_ARG;
+    if (B < 0 || (want & ~7) || want == 0) return fail(e, BK_ERR_ARG, "bad B or want mask");
+    if (B > e->max_batch) return fail(e, BK_ERR_BATCH, "B exceeds max_batch given at bk_engine_create");
+    if ((want & (BK_WANT_LOGITS | BK_WANT_PROBS)) && !e->has_policy)
+        return fail(e, BK_ERR_NO_NET, "policy outputs requested but the engine has no PolicyNet");
+    if ((want & BK_WANT_VALUE) && !e->has_value)
+        return fail(e, BK_ERR_NO_NET, "value requested but the engine has no ValueNet");
+    return BK_OK;
+}
+
+void drain_events(bk_engine* e) {
+    // fold finished (start, stop) pairs into the stats; called with the stream idle
+    const size_t n = e->ev_ring.size();
+    while (e->ev_pending) {
+        const size_t i = (e->ev_head + n - e->ev_pending) % n;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->ev_ring[i].first, e->ev_ring[i].second) == hipSuccess) {
+            e->st.kernel_ms_sum += ms;
+            e->st.kernel_ms_count += 1;
+            e->st.last_kernel_ms = ms;
+        }
+        --e->ev_pending;
+    }
+}
+
+// enqueue one kernel launch on `stream`; all pointers are device pointers
+int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int want, float* d_logits, float* d_probs,
+            float* d_values, hipStream_t stream) {
+    if (B == 0) return BK_OK;
+    bk_eval_args a{};
+    a.net[0] = e->net[0];
+    a.net[1] = e->net[1];
+    a.feats = d_feats;
+    a.feats_dtype = dtype;
+    a.B = B;
+    a.net_mask = ((want & (BK_WANT_LOGITS | BK_WANT_PROBS)) ? 1 : 0) | ((want & BK_WANT_VALUE) ? 2 : 0);
+    a.logits = (want & BK_WANT_LOGITS) ? d_logits : nullptr;
+    a.probs = (want & BK_WANT_PROBS) ? d_probs : nullptr;
+    a.values = (want & BK_WANT_VALUE) ? d_values : nullptr;
+    const int nb = bk_pick_nb(B, a.net_mask == 3 ? 2 : 1, e->n_cu);
+    bool timed = false;
+    size_t slot = 0;
+    if (e->profiling) {
+        if (e->ev_pending == e->ev_ring.size()) {  // ring full: wait for the stream and fold
+            HIP_TRY(e, hipStreamSynchronize(stream));
+            drain_events(e);
+        }
+        slot = e->ev_head;
+        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].first, stream));
+        timed = true;
+    }
+    HIP_TRY(e, bk_launch_leaf_eval(a, nb, stream));
+    if (timed) {
+        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
+        e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
+        ++e->ev_pending;
+    }
+    e->st.evals += (uint64_t)B;
+    e->st.batches += 1;
+    if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
+    return BK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_abi_version(void) { return BK_ABI_VERSION; }
+
+int bk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* value, int device_id, int max_batch,
+                     bk_engine** out) {
+    if (!out) return fail(nullptr, BK_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!policy && !value) return fail(nullptr, BK_ERR_ARG, "at least one of policy/value weights is required");
+    if (max_batch <= 0) return fail(nullptr, BK_ERR_ARG, "max_batch must be positive");
+    if (policy && !trunk_ok(policy->trunk)) return fail(nullptr, BK_ERR_ARG, "policy weights: NULL tensor pointer");
+    if (value) {
+        const bk_value_head_weights& h = value->head;
+        if (!trunk_ok(value->trunk) || !h.bn_w || !h.bn_b || !h.bn_mean || !h.bn_var || !h.lin1_w || !h.lin1_b ||
+            !h.lin_bn_w || !h.lin_bn_b || !h.lin_bn_mean || !h.lin_bn_var || !h.lin2_w || !h.lin2_b)
+            return fail(nullptr, BK_ERR_ARG, "value weights: NULL tensor pointer");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, BK_ERR_NO_GPU, "no HIP device visible (the engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, BK_ERR_ARG, "device_id out of range");
+
+    bk_engine* e = new (std::nothrow) bk_engine();
+    if (!e) return fail(nullptr, BK_ERR_OOM, "host allocation failed");
+    e->device = device_id;
+    e->max_batch = max_batch;
+    e->has_policy = policy != nullptr;
+    e->has_value = value != nullptr;
+    int rc = BK_OK;
+    auto bail = [&](int code) {
+        g_create_error = e->err;
+        bk_engine_destroy(e);
+        return code;
+    };
+#define TRY_CREATE(call)                                                        \
+    do {                                                                        \
+        hipError_t _s = (call);                                                 \
+        if (_s != hipSuccess) {                                                 \
+            e->err = std::string(#call) + ": " + hipGetErrorString(_s);         \
+            return bail(_s == hipErrorOutOfMemory ? BK_ERR_OOM : BK_ERR_HIP);   \
+        }                                                                       \
+    } while (0)
+    TRY_CREATE(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    TRY_CREATE(hipGetDeviceProperties(&prop, device_id));
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        e->err = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
+        return bail(BK_ERR_NO_GPU);
+    }
+    TRY_CREATE(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+
+    if (policy) {
+        if ((rc = setup_trunk(e, policy->trunk, e->net[0], 1.0, 0.0))) return bail(rc);
+    }
+    if (value) {
+        const bk_value_head_weights& h = value->head;
+        const double s = (double)h.bn_w[0] / std::sqrt((double)h.bn_var[0] + kBnEps);
+        const double shift = (double)h.bn_b[0] - (double)h.bn_mean[0] * s;
+        if ((rc = setup_trunk(e, value->trunk, e->net[1], s, shift))) return bail(rc);
+        // lin1 (64,81) + BatchNorm1d(64) folded, stored transposed [81][64] for coalesced reads
+        std::vector<float> w1t(81 * 64), b1(64), w2(64);
+        for (int j = 0; j < 64; ++j) {
+            const double sj = (double)h.lin_bn_w[j] / std::sqrt((double)h.lin_bn_var[j] + kBnEps);
+            for (int q = 0; q < 81; ++q) w1t[q * 64 + j] = (float)((double)h.lin1_w[j * 81 + q] * sj);
+            b1[j] = (float)(((double)h.lin1_b[j] - (double)h.lin_bn_mean[j]) * sj + (double)h.lin_bn_b[j]);
+            w2[j] = h.lin2_w[j];
+        }
+        if ((rc = upload(e, w1t, &e->net[1].lin1_wt))) return bail(rc);
+        if ((rc = upload(e, b1, &e->net[1].lin1_b))) return bail(rc);
+        if ((rc = upload(e, w2, &e->net[1].lin2_w))) return bail(rc);
+        e->net[1].lin2_b = h.lin2_b[0];
+    }
+    for (auto& s : e->slots)
+        if ((rc = alloc_slot(e, s))) return bail(rc);
+    e->ev_ring.resize(512);
+    for (auto& p : e->ev_ring) {
+        TRY_CREATE(hipEventCreate(&p.first));
+        TRY_CREATE(hipEventCreate(&p.second));
+    }
+#undef TRY_CREATE
+    *out = e;
+    return BK_OK;
+}
+
+int bk_engine_destroy(bk_engine* e) {
+    if (!e) return BK_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& s : e->slots) free_slot(s);
+    for (auto& p : e->ev_ring) {
+        if (p.first) (void)hipEventDestroy(p.first);
+        if (p.second) (void)hipEventDestroy(p.second);
+    }
+    for (void* d : e->dev_allocs) (void)hipFree(d);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return BK_OK;
+}
+
+int64_t bk_submit(bk_engine* e, const void* feats, int feats_dtype, int B, int want, float* logits, float* probs,
+                  float* values) {
+    int rc = check_want(e, B, want);
+    if (rc) return rc;
+    if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
+    if (B > 0 && !feats) return fail(e, BK_ERR_ARG, "feats is NULL");
+    if (((want & BK_WANT_LOGITS) && !logits) || ((want & BK_WANT_PROBS) && !probs) || ((want & BK_WANT_VALUE) && !values))
+        return fail(e, BK_ERR_ARG, "an output requested in `want` has a NULL buffer");
+    Slot* s = nullptr;
+    for (auto& c : e->slots)
+        if (!c.busy) { s = &c; break; }
+    if (!s) return fail(e, BK_ERR_ARG, "more than BK_MAX_INFLIGHT tickets outstanding");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t esz = feats_dtype == BK_FEATS_U8 ? 1 : 4;
+    if (B > 0) {
+        std::memcpy(s->h_in, feats, (size_t)B * 2187 * esz);
+        HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->stream));
+        rc = enqueue(e, s->d_in, feats_dtype, B, want, s->d_logits, s->d_probs, s->d_values, e->stream);
+        if (rc) return rc;
+        if (want & BK_WANT_LOGITS)
+            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)B * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+        if (want & BK_WANT_PROBS)
+            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)B * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+        if (want & BK_WANT_VALUE)
+            HIP_TRY(e, hipMemcpyAsync(s->h_values, s->d_values, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipEventRecord(s->done, e->stream));
+    s->busy = true;
+    s->ticket = e->next_ticket++;
+    s->B = B;
+    s->want = want;
+    s->logits = logits;
+    s->probs = probs;
+    s->values = values;
+    return s->ticket;
+}
+
+int bk_wait(bk_engine* e, int64_t ticket) {
+    if (!e) return BK_ERR_ARG;
+    for (auto& s : e->slots) {
+        if (!s.busy || s.ticket != ticket) continue;
+        HIP_TRY(e, hipEventSynchronize(s.done));
+        if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_logits, (size_t)s.B * 81 * 4);
+        if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_probs, (size_t)s.B * 81 * 4);
+        if (s.want & BK_WANT_VALUE) std::memcpy(s.values, s.h_values, (size_t)s.B * 4);
+        s.busy = false;
+        return BK_OK;
+    }
+    return fail(e, BK_ERR_ARG, "unknown or already-waited ticket");
+}
+
+int bk_eval(bk_engine* e, const float* feats, int B, int want, float* logits, float* probs, float* values) {
+    const int64_t t = bk_submit(e, feats, BK_FEATS_F32, B, want, logits, probs, values);
+    if (t < 0) return (int)t;
+    return bk_wait(e, t);
+}
+
+int bk_eval_u8(bk_engine* e, const uint8_t* feats, int B, int want, float* logits, float* probs, float* values) {
+    const int64_t t = bk_submit(e, feats, BK_FEATS_U8, B, want, logits, probs, values);
+    if (t < 0) return (int)t;
+    return bk_wait(e, t);
+}
+
+int bk_eval_device(bk_engine* e, const void* d_feats, int feats_dtype, int B, int want, float* d_logits,
+                   float* d_probs, float* d_values, void* stream) {
+    int rc = check_want(e, B, want);
+    if (rc) return rc;
+    if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
+    if (B > 0 && !d_feats) return fail(e, BK_ERR_ARG, "d_feats is NULL");
+    if (((want & BK_WANT_LOGITS) && !d_logits) || ((want & BK_WANT_PROBS) && !d_probs) ||
+        ((want & BK_WANT_VALUE) && !d_values))
+        return fail(e, BK_ERR_ARG, "an output requested in `want` has a NULL buffer");
+    HIP_TRY(e, hipSetDevice(e->device));
+    return enqueue(e, d_feats, feats_dtype, B, want, d_logits, d_probs, d_values,
+                   stream ? static_cast<hipStream_t>(stream) : e->stream);
+}
+
+int bk_engine_set_profiling(bk_engine* e, int on) {
+    if (!e) return BK_ERR_ARG;
+    e->profiling = on != 0;
+    return BK_OK;
+}
+
+int bk_engine_synchronize(bk_engine* e) {
+    if (!e) return BK_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return BK_OK;
+}
+
+int bk_stats(bk_engine* e, bk_stats_t* out) {
+    if (!e || !out) return BK_ERR_ARG;
+    if (e->ev_pending) {
+        // events may sit on a caller-provided stream: a device sync covers both cases
+        HIP_TRY(e, hipSetDevice(e->device));
+        HIP_TRY(e, hipDeviceSynchronize());
+        drain_events(e);
+    }
+    *out = e->st;
+    return BK_OK;
+}
+
+int bk_engine_max_batch(bk_engine* e) { return e ? e->max_batch : BK_ERR_ARG; }
+
+const char* bk_last_error(bk_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+// bk_kernels.hip -- the fused leaf-evaluation kernel for gfx950 (MI355X / CDNA4).
+//
+// Replaces, for a batch of positions, the reference's two forward passes
+//   PolicyNet.forward  (bokego/nnet.py:31-57)   + SOFT (nnet.py:16,273)
+//   ValueNet.forward   (bokego/nnet.py:73-113)
+// One workgroup (4 waves, one per SIMD) owns NB whole boards of ONE net and runs the whole
+// network on them without leaving the CU:
+//   * the NB x 81 x 128 fp32 activations live in LDS, position-major, in a "shared halo"
+//     layout (10-column rows: the zero column between two board rows is the right halo of
+//     one and the left halo of the next, a zero row separates boards), so every 3x3 tap is a
+//     constant address offset and needs no bounds test; 16-byte chunks are XOR-swizzled by
+//     the position so the 32 rows of an MFMA A-fragment hit distinct LDS slots;
+//   * each conv layer is an implicit GEMM  [32*MT rows] x [128 couts] x [taps*cin]  on the
+//     exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32; wave w owns couts 32w..32w+31 for
+//     ALL rows, so every weight is fetched by exactly one wave, straight from L2 into
+//     registers, in a host-prepacked fragment order (one coalesced 1 KiB read per 8 cin);
+//   * the layer output stays in the accumulators until every wave has finished reading the
+//     layer input, then is written back IN PLACE (bias + ReLU fused): no ping-pong buffer,
+//     which is what lets 3 boards (159 KB) fit the 160 KB LDS;
+//   * the untied-bias 1x1 head, the 81-way softmax and the value MLP + tanh are wave-level
+//     reductions at the end of the same kernel.
+// HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2
+// resident).  BatchNorm (eval mode) is folded into the weights on the host in fp64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bk_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- LDS layouts -------------------------------------------------------------------------
+// 128-channel activations: position p = (10*b + 1 + y)*10 + (x + 1); 512 B per position.
+__device__ __forceinline__ int pos3(int b, int y, int x) { return (10 * b + 1 + y) * 10 + x + 1; }
+__device__ __forceinline__ int act_addr(int p, int c) { return p * 128 + ((((c >> 2) ^ (p & 15)) << 2) | (c & 3)); }
+// layer-0 input (27 channels padded to 32): 11-column rows with two shared halo columns,
+// two zero rows between boards (5x5 taps); 128 B per position.
+__device__ __forceinline__ int pos5(int b, int y, int x) { return (11 * b + 2 + y) * 11 + x + 2; }
+__device__ __forceinline__ int in_addr(int p, int c) { return p * 32 + ((((c >> 2) ^ ((p >> 1) & 7)) << 2) | (c & 3)); }
+
+template <int NB>
+struct Geo {
+    static constexpr int MT = (81 * NB + 31) / 32;  // 32-row MFMA tiles
+    static constexpr int NPOS = 100 * NB + 11;      // positions in the 128-ch layout
+    static constexpr int NP0 = 121 * NB + 24;       // positions in the layer-0 layout
+    static constexpr int ROWPOS_FLOATS = MT * 16;   // MT*32 int16
+    static constexpr int HS_FLOATS = NB * 96;
+    static constexpr int LDS_BYTES = (NPOS * 128 + ROWPOS_FLOATS + HS_FLOATS) * 4;
+};
+
+// One conv layer: acc[mt] (32 rows x 32 couts of this wave) = sum over taps, cin.
+// wl: this wave's slice of the layer's fragment-ordered weights.
+template <int NB, bool FIRST>
+__device__ __forceinline__ void conv_layer(const float* act, const float* __restrict__ wl,
+                                           f32x16 (&acc)[Geo<NB>::MT], int lane) {
+    constexpr int MT = Geo<NB>::MT;
+    constexpr int KW = FIRST ? 5 : 3;
+    constexpr int TAPS = KW * KW;
+    constexpr int NBLK = FIRST ? 1 : 4;  // blocks of 4 channel-groups (8 cin each) per tap
+    const int h = lane >> 5, l32 = lane & 31;
+
+    int pbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r = mt * 32 + l32;
+        if (r >= 81 * NB) r = 0;  // padding rows compute garbage from a valid address; never stored
+        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
+        pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + lane;
+    f32x4 Bc[4], Bn[4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) Bc[gg] = wp[gg * 64];
+
+#pragma unroll 1
+    for (int t = 0; t < TAPS; ++t) {
+        const int ky = t / KW, kx = t - ky * KW;
+        const int off = FIRST ? (ky - 2) * 11 + (kx - 2) : (ky - 1) * 10 + (kx - 1);
+        int abase[MT], sw[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pa = pbase[mt] + off;
+            abase[mt] = FIRST ? pa * 32 : pa * 128;
+            sw[mt] = FIRST ? ((pa >> 1) & 7) : (pa & 15);
+        }
+#pragma unroll 1
+        for (int gb = 0; gb < NBLK; ++gb) {
+            const int blk = t * NBLK + gb;
+            // prefetch the next block's B fragments (one block = 4 KiB per wave) from L2
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) Bn[gg] = wp[((blk + 1) * 4 + gg) * 64];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int chunk = (gb * 4 + gg) * 2 + h;
+                f32x4 A[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    A[mt] = *reinterpret_cast<const f32x4*>(act + abase[mt] + ((chunk ^ sw[mt]) << 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt][j], Bc[gg][j], acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) Bc[gg] = Bn[gg];
+        }
+    }
+}
+
+// bias + ReLU + in-place store of this wave's 32 couts
+template <int NB>
+__device__ __forceinline__ void store_layer(float* act, const short* rowpos, const f32x16 (&acc)[Geo<NB>::MT],
+                                            float bias, int col, int h) {
+    constexpr int MT = Geo<NB>::MT;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int p = rowpos[r];
+            if (p >= 0) {
+                float v = acc[mt][i] + bias;
+                act[act_addr(p, col)] = v > 0.f ? v : 0.f;
+            }
+        }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a) {
+    using G = Geo<NB>;
+    constexpr int MT = G::MT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    short* rowpos = reinterpret_cast<short*>(smem + G::NPOS * 128);
+    float* hs = smem + G::NPOS * 128 + G::ROWPOS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+
+    // block -> (net, task).  With both nets, blocks b and b+8 share an XCD (round-robin
+    // dispatch): bit 2 of the block id picks the net, so each XCD's L2 streams ONE net's
+    // 3.9 MB of weights (speed only; any placement is correct).
+    int net, task;
+    const int bid = blockIdx.x;
+    if (a.net_mask == 3) {
+        net = (bid >> 2) & 1;
+        task = ((bid >> 3) << 2) | (bid & 3);
+    } else {
+        net = a.net_mask == 2 ? 1 : 0;
+        task = bid;
+    }
+    if (task >= a.tasks) return;
+    const bk_net_params& P = a.net[net];
+    const int b0 = task * NB;
+    const int nb = min(NB, a.B - b0);
+
+    // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
+    for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = tid; r < MT * 32; r += 256) {
+        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
+        rowpos[r] = r < 81 * NB ? (short)pos3(b, y, x) : (short)-1;
+    }
+    __syncthreads();
+    if (a.feats_dtype == BK_FEATS_F32_) {
+        const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
+        for (int e = tid; e < nb * 2187; e += 256) {
+            const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
+            act[in_addr(pos5(b, y, x), c)] = X[e];
+        }
+    } else {
+        const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
+        for (int e = tid; e < nb * 2187; e += 256) {
+            const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
+            act[in_addr(pos5(b, y, x), c)] = (float)X[e];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[MT];
+    const int col = 32 * wave + (lane & 31);
+
+    // ---- layer 0: 5x5, 27(32) -> 128 ----
+    conv_layer<NB, true>(act, P.wfrag + wave * (BK_L0_WAVE_FLOATS), acc, lane);
+    __syncthreads();  // everyone done reading the input planes
+    // the 128-ch layout overlaps the input region: clear it all (halo must be zero)
+    for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    store_layer<NB>(act, rowpos, acc, P.bias[col], col, h);
+    __syncthreads();
+
+    // ---- layers 1..6: 3x3, 128 -> 128, in place ----
+#pragma unroll 1
+    for (int L = 1; L < 7; ++L) {
+        conv_layer<NB, false>(act, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS + wave * BK_L3_WAVE_FLOATS, acc, lane);
+        __syncthreads();
+        store_layer<NB>(act, rowpos, acc, P.bias[L * 128 + col], col, h);
+        __syncthreads();
+    }
+
+    // ---- heads: wave w handles board w ----
+    if (wave < nb) {
+        float s[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = lane + 64 * k;
+            float d = 0.f;
+            if (q < 81) {
+                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x);
+                const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
+#pragma unroll 8
+                for (int cc = 0; cc < 32; ++cc) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(act + p * 128 + ((cc ^ (p & 15)) << 2));
+                    const f32x4 w = hw[cc];
+                    d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
+                }
+                d += P.head_b[q];
+            }
+            s[k] = d;
+        }
+        const int bg = b0 + wave;
+        if (net == 0) {
+            // PolicyNet: logits = head; probs = softmax
+            const float m = wave_max(fmaxf(s[0], (lane + 64 < 81) ? s[1] : -INFINITY));
+            const float e0 = expf(s[0] - m);
+            const float e1 = (lane + 64 < 81) ? expf(s[1] - m) : 0.f;
+            const float inv = 1.f / wave_sum(e0 + e1);
+            if (a.logits) {
+                a.logits[(size_t)bg * 81 + lane] = s[0];
+                if (lane + 64 < 81) a.logits[(size_t)bg * 81 + lane + 64] = s[1];
+            }
+            if (a.probs) {
+                a.probs[(size_t)bg * 81 + lane] = e0 * inv;
+                if (lane + 64 < 81) a.probs[(size_t)bg * 81 + lane + 64] = e1 * inv;
+            }
+        } else {
+            // ValueNet: (BN2d folded) ReLU -> lin1 (BN1d folded) -> ReLU -> lin2 -> tanh
+            float* hv = hs + wave * 96;
+            hv[lane] = fmaxf(s[0], 0.f);
+            if (lane + 64 < 81) hv[lane + 64] = fmaxf(s[1], 0.f);
+            __builtin_amdgcn_wave_barrier();
+            float z = P.lin1_b[lane];
+#pragma unroll 9
+            for (int q = 0; q < 81; ++q) z += P.lin1_wt[q * 64 + lane] * hv[q];
+            z = fmaxf(z, 0.f);
+            const float v = wave_sum(z * P.lin2_w[lane]) + P.lin2_b;
+            if (lane == 0 && a.values) a.values[bg] = tanhf(v);
+        }
+    }
+}
+
+template <int NB>
+hipError_t launch_nb(const bk_eval_args& a, int nets, hipStream_t stream) {
+    static bool attr_set = false;
+    auto kern = bk_leaf_eval_kernel<NB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NB>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    bk_eval_args args = a;
+    args.tasks = (a.B + NB - 1) / NB;
+    const int grid = nets == 2 ? 8 * ((args.tasks + 3) / 4) : args.tasks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Geo<NB>::LDS_BYTES, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Picks boards-per-workgroup so that (rounds over the CUs) x (MFMA tiles per workgroup) is minimal.
+int bk_pick_nb(int B, int nets, int n_cu) {
+    const int mt[4] = {0, 3, 6, 8};
+    int best = 3;
+    long best_cost = -1;
+    for (int nb = 3; nb >= 1; --nb) {
+        const long wgs = (long)nets * ((B + nb - 1) / nb);
+        const long per_cu = nb == 1 ? 2 : 1;  // NB=1 fits two workgroups per CU (57 KB LDS each)
+        const long rounds = (wgs + n_cu * per_cu - 1) / (n_cu * per_cu);
+        const long cost = rounds * mt[nb];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
+hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {
+    const int nets = a.net_mask == 3 ? 2 : 1;
+    switch (nb) {
+        case 1: return launch_nb<1>(a, nets, stream);
+        case 2: return launch_nb<2>(a, nets, stream);
+        default: return launch_nb<3>(a, nets, stream);
+    }
+}

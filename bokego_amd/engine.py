@@ -1,0 +1,200 @@
+"""LeafEngine: Python handle of one bk_engine (one HIP stream on one MI355X).
+
+Batches positions through the fused HIP kernel.  Mirrors what the reference does one
+position at a time in nnet.policy_dist / nnet.value (bokego/nnet.py:265-284).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+_CONV = (0, 3, 6, 9, 12, 15, 18)
+_BN = (1, 4, 7, 10, 13, 16, 19)
+
+
+def _np32(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(L.c_float_p)
+
+
+def _fill_trunk(t, sd, keep):
+    def get(name, size):
+        if name not in sd:
+            raise KeyError(f"state_dict is missing '{name}'")
+        a = _np32(sd[name]).reshape(-1)
+        if a.size != size:
+            raise ValueError(f"'{name}' has {a.size} elements, expected {size}")
+        keep.append(a)
+        return _ptr(a)
+
+    for l, (c, b) in enumerate(zip(_CONV, _BN)):
+        t.conv_w[l] = get(f"conv.{c}.weight", 128 * (27 * 25 if l == 0 else 128 * 9))
+        t.conv_b[l] = get(f"conv.{c}.bias", 128)
+        t.bn_w[l] = get(f"conv.{b}.weight", 128)
+        t.bn_b[l] = get(f"conv.{b}.bias", 128)
+        t.bn_mean[l] = get(f"conv.{b}.running_mean", 128)
+        t.bn_var[l] = get(f"conv.{b}.running_var", 128)
+    t.head_w = get("conv.21.weight", 128)
+    t.head_b = get("conv.21.bias", 81)
+
+
+_HEAD_KEYS = (("bn_w", "bn.weight", 1), ("bn_b", "bn.bias", 1), ("bn_mean", "bn.running_mean", 1),
+              ("bn_var", "bn.running_var", 1), ("lin1_w", "lin1.weight", 64 * 81), ("lin1_b", "lin1.bias", 64),
+              ("lin_bn_w", "lin_bn.weight", 64), ("lin_bn_b", "lin_bn.bias", 64),
+              ("lin_bn_mean", "lin_bn.running_mean", 64), ("lin_bn_var", "lin_bn.running_var", 64),
+              ("lin2_w", "lin2.weight", 64), ("lin2_b", "lin2.bias", 1))
+
+
+class LeafEngine:
+    """policy_sd / value_sd: mappings with the reference state_dict names (torch tensors or arrays)."""
+
+    def __init__(self, policy_sd=None, value_sd=None, device_id=0, max_batch=4096):
+        if policy_sd is None and value_sd is None:
+            raise TypeError("LeafEngine needs policy and/or value weights")
+        lib = L.load()
+        keep = []
+        pw = vw = None
+        if policy_sd is not None:
+            pw = L.PolicyWeights()
+            _fill_trunk(pw.trunk, policy_sd, keep)
+        if value_sd is not None:
+            vw = L.ValueWeights()
+            _fill_trunk(vw.trunk, value_sd, keep)
+            for field, name, size in _HEAD_KEYS:
+                if name not in value_sd:
+                    raise KeyError(f"state_dict is missing '{name}'")
+                a = _np32(value_sd[name]).reshape(-1)
+                if a.size != size:
+                    raise ValueError(f"'{name}' has {a.size} elements, expected {size}")
+                keep.append(a)
+                setattr(vw.head, field, _ptr(a))
+        h = ctypes.c_void_p()
+        rc = lib.bk_engine_create(ctypes.byref(pw) if pw is not None else None,
+                                  ctypes.byref(vw) if vw is not None else None, int(device_id), int(max_batch),
+                                  ctypes.byref(h))
+        if rc != L.BK_OK:
+            raise RuntimeError(f"bk_engine_create failed: {L.STATUS_NAMES.get(rc, rc)}: "
+                               f"{lib.bk_last_error(None).decode()}")
+        self._lib, self._h = lib, h
+        self.device_id, self.max_batch = int(device_id), int(max_batch)
+        self.has_policy, self.has_value = policy_sd is not None, value_sd is not None
+        self._pending = {}
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.bk_last_error(self._h).decode()
+            name = L.STATUS_NAMES.get(rc, str(rc))
+            if rc in (-1, -4, -5):
+                raise ValueError(f"{name}: {msg}")
+            raise RuntimeError(f"{name}: {msg}")
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bk_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _want(logits, probs, value):
+        return (L.BK_WANT_LOGITS if logits else 0) | (L.BK_WANT_PROBS if probs else 0) | (L.BK_WANT_VALUE if value else 0)
+
+    @staticmethod
+    def _feats(feats):
+        a = np.asarray(feats)
+        if a.dtype == np.uint8 or a.dtype == np.int8:
+            a = np.ascontiguousarray(a).view(np.uint8)
+            dt = L.BK_FEATS_U8
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            dt = L.BK_FEATS_F32
+        if a.ndim == 3:
+            a = a[None]
+        if a.ndim != 4 or a.shape[1:] != (27, 9, 9):
+            raise ValueError(f"features must be [B,27,9,9], got {a.shape}")
+        return a, dt
+
+    # -- host-buffer API -------------------------------------------------------------------
+    def submit(self, feats, logits=False, probs=True, value=True):
+        """Asynchronous evaluation of host features; returns a ticket for wait()."""
+        a, dt = self._feats(feats)
+        B = a.shape[0]
+        want = self._want(logits, probs, value)
+        out = {}
+        if logits:
+            out["logits"] = np.empty((B, 81), np.float32)
+        if probs:
+            out["probs"] = np.empty((B, 81), np.float32)
+        if value:
+            out["value"] = np.empty((B,), np.float32)
+        p = lambda k: out[k].ctypes.data if k in out else None  # noqa: E731
+        t = self._check(self._lib.bk_submit(self._h, a.ctypes.data, dt, B, want, p("logits"), p("probs"), p("value")))
+        self._pending[t] = (a, out)
+        return t
+
+    def wait(self, ticket):
+        a, out = self._pending.pop(ticket)
+        self._check(self._lib.bk_wait(self._h, ticket))
+        return out
+
+    def eval(self, feats, logits=False, probs=True, value=True):
+        """Synchronous: dict with the requested 'logits' [B,81], 'probs' [B,81], 'value' [B]."""
+        return self.wait(self.submit(feats, logits=logits, probs=probs, value=value))
+
+    # -- device-resident API (torch CUDA/HIP tensors) -------------------------------------
+    def eval_device(self, d_feats, logits=False, probs=True, value=True, stream=None):
+        """d_feats: torch tensor on this engine's GPU, float32 or uint8 [B,27,9,9].
+        Runs on torch's current stream (or `stream`); returns dict of torch tensors."""
+        import torch
+
+        if not d_feats.is_cuda or d_feats.device.index != self.device_id:
+            raise ValueError("eval_device needs a tensor on the engine's GPU")
+        x = d_feats.contiguous()
+        if x.dtype == torch.uint8:
+            dt = L.BK_FEATS_U8
+        elif x.dtype == torch.float32:
+            dt = L.BK_FEATS_F32
+        else:
+            raise ValueError("features must be float32 or uint8")
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (27, 9, 9):
+            raise ValueError(f"features must be [B,27,9,9], got {tuple(x.shape)}")
+        B = x.shape[0]
+        out = {}
+        if logits:
+            out["logits"] = torch.empty((B, 81), dtype=torch.float32, device=x.device)
+        if probs:
+            out["probs"] = torch.empty((B, 81), dtype=torch.float32, device=x.device)
+        if value:
+            out["value"] = torch.empty((B,), dtype=torch.float32, device=x.device)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device).cuda_stream
+        p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
+        self._check(self._lib.bk_eval_device(self._h, x.data_ptr(), dt, B, self._want(logits, probs, value),
+                                             p("logits"), p("probs"), p("value"), ctypes.c_void_p(s)))
+        out["_keepalive"] = x
+        return out
+
+    # -- misc ---------------------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._check(self._lib.bk_engine_set_profiling(self._h, int(on)))
+
+    def synchronize(self):
+        self._check(self._lib.bk_engine_synchronize(self._h))
+
+    def stats(self):
+        s = L.Stats()
+        self._check(self._lib.bk_stats(self._h, ctypes.byref(s)))
+        return {f: getattr(s, f) for f, _ in L.Stats._fields_}

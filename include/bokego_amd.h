@@ -1,0 +1,139 @@
+/*
+ * bokego_amd.h -- C ABI of the MI355X leaf-evaluation engine (libbokego_amd.so).
+ *
+ * The reference (meiji163/bokego) has no FFI: its device boundary is the pair of Python
+ * callables policy_net(x[B,27,9,9]) -> [B,81] and value_net(x) -> [B,1] invoked from
+ *   bokego/nnet.py:265-275  policy_dist()  -> SOFT(policy(fts))      (one position per call)
+ *   bokego/nnet.py:277-284  value()        -> v(fts).item()          (blocking)
+ *   bokego/nnet.py:286-297  policy_sample()
+ *   bokego/mcts.py:371-403  Go_MCTS.dist / .value  (the cache-miss path = "evaluate a leaf")
+ * Each entry point below cites the reference interface it replaces.  All pointers are plain
+ * host (or, where stated, device) pointers; no torch types cross this boundary.
+ *
+ * Conventions: every function returns BK_OK (0) or a negative bk_status; the message of the
+ * last failure on an engine is available from bk_last_error().  One engine = one HIP stream =
+ * one consumer thread (the reference calls the nets from a single thread, gtp.py:98-108);
+ * several engines per process/device are allowed.
+ */
+#ifndef BOKEGO_AMD_H
+#define BOKEGO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_ABI_VERSION 1
+
+typedef enum bk_status {
+    BK_OK = 0,
+    BK_ERR_ARG = -1,     /* null/invalid argument                                      */
+    BK_ERR_HIP = -2,     /* a HIP runtime call failed (message has the hipError string) */
+    BK_ERR_OOM = -3,     /* host or device allocation failed                           */
+    BK_ERR_BATCH = -4,   /* B > max_batch given at create                              */
+    BK_ERR_NO_NET = -5,  /* output requested from a net the engine was created without */
+    BK_ERR_NO_GPU = -6   /* no usable HIP device                                       */
+} bk_status;
+
+/* bits of `want` */
+#define BK_WANT_LOGITS 1 /* PolicyNet.forward output, nnet.py:54-57            */
+#define BK_WANT_PROBS 2  /* SOFT(logits), nnet.py:16,273                        */
+#define BK_WANT_VALUE 4  /* ValueNet.forward output (after tanh), nnet.py:109-113 */
+
+/* feature dtypes accepted by the *_device / submit entry points */
+#define BK_FEATS_F32 0 /* float32 [B,27,9,9] NCHW: exactly nnet.features() output, nnet.py:182-262 */
+#define BK_FEATS_U8 1  /* uint8   [B,27,9,9] NCHW: same planes (values 0..7) as bytes             */
+
+/*
+ * Unfolded weights under their reference state_dict names (nnet.py:31-53 / 73-101).
+ * Block l (0..6) = conv.{3l} (Conv2d) + conv.{3l+1} (BatchNorm2d); head = conv.21
+ * (Conv2dUntiedBias, nnet.py:138-180).  BatchNorm is folded inside bk_engine_create, in fp64.
+ */
+typedef struct bk_trunk_weights {
+    const float *conv_w[7];  /* [0]: (128,27,5,5)  [1..6]: (128,128,3,3), OIHW */
+    const float *conv_b[7];  /* (128)                                          */
+    const float *bn_w[7];    /* BatchNorm2d weight (gamma) (128)               */
+    const float *bn_b[7];    /* BatchNorm2d bias (beta)                        */
+    const float *bn_mean[7]; /* running_mean                                   */
+    const float *bn_var[7];  /* running_var, eps = 1e-5                        */
+    const float *head_w;     /* conv.21.weight (1,128,1,1)                     */
+    const float *head_b;     /* conv.21.bias   (1,9,9) untied                  */
+} bk_trunk_weights;
+
+typedef struct bk_value_head_weights { /* nnet.py:96-101 */
+    const float *bn_w, *bn_b, *bn_mean, *bn_var;             /* BatchNorm2d(1): 1 element each */
+    const float *lin1_w, *lin1_b;                            /* (64,81), (64)                  */
+    const float *lin_bn_w, *lin_bn_b, *lin_bn_mean, *lin_bn_var; /* BatchNorm1d(64)             */
+    const float *lin2_w, *lin2_b;                            /* (1,64), (1)                    */
+} bk_value_head_weights;
+
+typedef struct bk_policy_weights {
+    bk_trunk_weights trunk;
+} bk_policy_weights;
+
+typedef struct bk_value_weights {
+    bk_trunk_weights trunk;
+    bk_value_head_weights head;
+} bk_value_weights;
+
+typedef struct bk_engine bk_engine;
+
+typedef struct bk_stats_t {
+    uint64_t evals;          /* positions evaluated                          */
+    uint64_t batches;        /* kernel launches                              */
+    uint64_t max_batch_seen;
+    double kernel_ms_sum;    /* sum of HIP-event kernel durations (profiling on) */
+    uint64_t kernel_ms_count;
+    double last_kernel_ms;
+} bk_stats_t;
+
+int bk_abi_version(void);
+int bk_device_count(void);
+
+/*
+ * Replaces: PolicyNet()/ValueNet() construction + load_state_dict + .eval() + .to(device)
+ * (boke.py:30-38, mcts.py:74-76).  Either net may be NULL (not both).  Weights are copied;
+ * caller memory is not referenced after return.  max_batch bounds B of every later call.
+ */
+int bk_engine_create(const bk_policy_weights *policy, const bk_value_weights *value, int device_id,
+                     int max_batch, bk_engine **out);
+int bk_engine_destroy(bk_engine *e);
+
+/*
+ * Replaces: policy(fts) / v(fts) on host tensors (nnet.py:272-273, 283-284), batched.
+ * feats: host float32 [B,27,9,9]; logits/probs: host [B,81]; values: host [B].
+ * Output pointers for bits not in `want` may be NULL.  Synchronous.
+ */
+int bk_eval(bk_engine *e, const float *feats, int B, int want, float *logits, float *probs, float *values);
+/* same with uint8 feature planes (4x less PCIe traffic) */
+int bk_eval_u8(bk_engine *e, const uint8_t *feats, int B, int want, float *logits, float *probs, float *values);
+
+/*
+ * Device-resident variant (the reference's `--gpu` path keeps tensors on the device,
+ * nnet.py:272 `.to(device)`): all pointers are device pointers on the engine's device.
+ * `stream` is a hipStream_t (NULL = the engine's own stream).  Asynchronous on that stream.
+ */
+int bk_eval_device(bk_engine *e, const void *d_feats, int feats_dtype, int B, int want, float *d_logits,
+                   float *d_probs, float *d_values, void *stream);
+
+/*
+ * Asynchronous host-buffer variant for the batched leaf queue: returns a ticket (>0) or a
+ * negative bk_status.  Host buffers must stay alive until bk_wait(ticket) returns.  At most
+ * BK_MAX_INFLIGHT tickets may be outstanding.
+ */
+#define BK_MAX_INFLIGHT 4
+int64_t bk_submit(bk_engine *e, const void *feats, int feats_dtype, int B, int want, float *logits, float *probs,
+                  float *values);
+int bk_wait(bk_engine *e, int64_t ticket);
+
+int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every kernel launch */
+int bk_stats(bk_engine *e, bk_stats_t *out);
+int bk_engine_max_batch(bk_engine *e);
+int bk_engine_synchronize(bk_engine *e);
+const char *bk_last_error(bk_engine *e); /* e == NULL: last error of a failed create */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOKEGO_AMD_H */

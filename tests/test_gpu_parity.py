@@ -1,0 +1,149 @@
+"""-m gpu: the HIP engine (through the C ABI) vs the CPU oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from bokego_amd.bkw import load_bkw
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGIT = 1e-4  # BASELINE.json north_star: "within 1e-4 fp32"
+TOL_VALUE = 1e-4
+TOL_PROB = 1e-5
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+
+
+@pytest.fixture(scope="module")
+def engine(weights):
+    from bokego_amd.engine import LeafEngine
+    e = LeafEngine(weights[0], weights[1], device_id=0, max_batch=4096)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oracle(weights):
+    from oracle.oracle import OraclePolicy, OracleValue
+    return OraclePolicy(weights[0]), OracleValue(weights[1])
+
+
+@pytest.fixture(scope="module")
+def gold():
+    f = np.load(os.path.join(GOLDEN, "features.npz"))["incremental"]
+    n = np.load(os.path.join(GOLDEN, "nets.npz"))
+    return f, n
+
+
+def _check(out, lg, pr, va):
+    assert np.abs(out["logits"] - lg).max() < TOL_LOGIT
+    assert np.abs(out["probs"] - pr).max() < TOL_PROB
+    assert np.abs(out["value"] - va).max() < TOL_VALUE
+
+
+def test_config1_single_positions_vs_reference(engine, gold):
+    """BASELINE config 1: every golden position one at a time (B=1)."""
+    f, n = gold
+    for i in range(len(f)):
+        out = engine.eval(f[i].astype(np.float32), logits=True, probs=True, value=True)
+        _check(out, n["logits_b1"][i:i + 1], n["probs_b1"][i:i + 1], n["values_b1"][i:i + 1])
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 64, 243, 244, 536])
+def test_batched_vs_reference_goldens(engine, gold, B):
+    f, n = gold
+    out = engine.eval(f[:B].astype(np.float32), logits=True, probs=True, value=True)
+    _check(out, n["logits_b1"][:B], n["probs_b1"][:B], n["values_b1"][:B])
+
+
+def test_uint8_features_identical(engine, gold):
+    f, _ = gold
+    a = engine.eval(f.astype(np.float32), logits=True, probs=True, value=True)
+    b = engine.eval(f.astype(np.uint8), logits=True, probs=True, value=True)
+    for k in ("logits", "probs", "value"):
+        assert np.array_equal(a[k], b[k])
+
+
+def test_playout_positions(engine):
+    p = np.load(os.path.join(GOLDEN, "playouts.npz"))
+    out = engine.eval(p["features"], logits=True, probs=False, value=True)
+    assert np.abs(out["logits"] - p["logits"]).max() < TOL_LOGIT
+    assert np.abs(out["value"] - p["values"]).max() < TOL_VALUE
+
+
+def test_vs_oracle_random_inputs(engine, oracle):
+    """iid random planes (values 0..7): far from the golden distribution, checked against the oracle.
+    Logits on such inputs are much larger than on real positions, so the bound scales with them."""
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 8, size=(96, 27, 9, 9)).astype(np.float32)
+    out = engine.eval(x, logits=True, probs=False, value=True)
+    lg = oracle[0](x)
+    scale = max(1.0, np.abs(lg).max() / 50.0)
+    assert np.abs(out["logits"] - lg).max() < TOL_LOGIT * scale
+    assert np.abs(out["value"] - oracle[1](x)).max() < 1e-3
+
+
+def test_full_batch_4096_properties(engine, gold, oracle):
+    """BASELINE config 2 size: batch invariance + slot invariance + oracle spot check."""
+    f, n = gold
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, len(f), size=4096)
+    x = f[idx].astype(np.float32)
+    out = engine.eval(x, logits=True, probs=True, value=True)
+    # every copy of a position gives the same answer as its B=1 golden, wherever it sits in the batch
+    _check(out, n["logits_b1"][idx], n["probs_b1"][idx], n["values_b1"][idx])
+    # bit-exact slot invariance: same input -> same bits regardless of its slot in the batch
+    first = {}
+    for j, i in enumerate(idx):
+        if i in first:
+            assert np.array_equal(out["logits"][j], out["logits"][first[i]])
+            assert out["value"][j] == out["value"][first[i]]
+        else:
+            first[i] = j
+    assert np.allclose(out["probs"].sum(1), 1.0, atol=1e-5)
+    sel = rng.integers(0, 4096, size=64)
+    assert np.abs(out["logits"][sel] - oracle[0](x[sel])).max() < TOL_LOGIT
+
+
+def test_single_net_engines(weights, gold):
+    from bokego_amd.engine import LeafEngine
+    f, n = gold
+    pe = LeafEngine(policy_sd=weights[0], max_batch=64)
+    ve = LeafEngine(value_sd=weights[1], max_batch=64)
+    x = f[:50].astype(np.float32)
+    o = pe.eval(x, logits=True, probs=True, value=False)
+    assert np.abs(o["logits"] - n["logits_b1"][:50]).max() < TOL_LOGIT
+    v = ve.eval(x, logits=False, probs=False, value=True)
+    assert np.abs(v["value"] - n["values_b1"][:50]).max() < TOL_VALUE
+    with pytest.raises(ValueError):
+        pe.eval(x, logits=False, probs=False, value=True)      # BK_ERR_NO_NET
+    with pytest.raises(ValueError):
+        pe.eval(f[:65].astype(np.float32), probs=True, value=False)  # BK_ERR_BATCH
+    pe.close()
+    ve.close()
+
+
+def test_async_tickets(engine, gold):
+    f, n = gold
+    x = f.astype(np.float32)
+    t = [engine.submit(x[i * 100:(i + 1) * 100], logits=True, probs=False, value=True) for i in range(4)]
+    for i in reversed(range(4)):
+        o = engine.wait(t[i])
+        assert np.abs(o["logits"] - n["logits_b1"][i * 100:(i + 1) * 100]).max() < TOL_LOGIT
+        assert np.abs(o["value"] - n["values_b1"][i * 100:(i + 1) * 100]).max() < TOL_VALUE
+
+
+def test_device_resident_path(engine, gold):
+    import torch
+    f, n = gold
+    x = torch.from_numpy(f[:300].astype(np.float32)).cuda()
+    o = engine.eval_device(x, logits=True, probs=True, value=True)
+    torch.cuda.synchronize()
+    _check({k: o[k].cpu().numpy() for k in ("logits", "probs", "value")},
+           n["logits_b1"][:300], n["probs_b1"][:300], n["values_b1"][:300])
