@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- leaf-evals/s of the fused PolicyNet+ValueNet HIP engine on MI355X.
+
+A "step" is one pass of the hot path over one batch: BASELINE.json configs[1], 4096 9x9
+positions, policy logits + softmax + value, inputs already resident in HBM.  With --gpus N
+(launched through torch.distributed.run, one rank per GPU) every rank evaluates its own 4096
+positions per step: the path shards with no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+  roofline      bound = fp32 MFMA (266,838,272 algorithmic FLOP per leaf-eval,
+                peak 157.3 TFLOP/s), kernel time from HIP events on the launch stream
+  cpu_baseline  the CPU oracle (oracle/nnet_ref.c, a port of the reference's forward pass)
+                timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_LEAF = 266_838_272          # SURVEY 8d / BASELINE.md 3: valid taps, both nets
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md chip table
+BYTES_PER_LEAF = 8748 + 328          # compulsory HBM bytes (f32 planes in, 81 probs + value out)
+BATCH = 4096
+
+
+def make_workload(B, seed):
+    """Synthetic batch: seeded resample of the golden feature planes (real game + random-playout
+    positions encoded by the reference's features()); dense-conv cost is data independent."""
+    g = os.path.join(REPO, "tests", "golden")
+    pool = np.concatenate([np.load(os.path.join(g, "features.npz"))["incremental"],
+                           np.load(os.path.join(g, "playouts.npz"))["features"]])
+    idx = np.random.default_rng(seed).integers(0, len(pool), size=B)
+    return pool[idx].astype(np.float32)
+
+
+def measured_traffic(batch):
+    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json,
+    produced by tools/profile_bench.sh + tools/summarize_prof.py); None if absent or another batch."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    if d.get("batch") != batch:
+        return None, None
+    return d.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
+def cpu_baseline(pw, vw, x, target_s=12.0):
+    from oracle.oracle import OraclePolicy, OracleValue, set_threads
+
+    P, V = OraclePolicy(pw), OracleValue(vw)
+    # a 1-GPU box gets a 16-core share of the host (more threads only fight over them)
+    cores = set_threads(int(os.environ.get("BK_CPU_THREADS", min(16, len(os.sched_getaffinity(0))))))
+    n = 64
+    t0 = time.time(); P(x[:n]); V(x[:n]); dt = time.time() - t0  # warm + calibrate
+    n = int(max(64, min(len(x), n * target_s / max(dt, 1e-3))))
+    t0 = time.time(); P(x[:n]); V(x[:n]); dt = time.time() - t0
+    return {"value": n / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} positions of the same batch, oracle/nnet_ref.c (OpenMP, fp32), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+
+    g = os.path.join(REPO, "tests", "golden")
+    pw, vw = load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, device_id=local_rank, max_batch=args.batch)
+    x_host = make_workload(args.batch, 20260 + rank)
+    x = torch.from_numpy(x_host).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.eval_device(x, logits=True, probs=True, value=True)
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    s0 = eng.stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.eval_device(x, logits=True, probs=True, value=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    eng.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])
+    assert torch.isfinite(out["value"]).all() and torch.isfinite(out["probs"]).all()
+
+    # PCIe-inclusive rate through the host-buffer ABI (reported beside, never as `value`)
+    e2e = None
+    if rank == 0:
+        eng.eval(x_host, logits=False, probs=True, value=True)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.eval(x_host, logits=False, probs=True, value=True)
+        e2e = 3 * args.batch / (time.perf_counter() - t1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pw, vw, x_host)
+
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        achieved = args.batch * FLOP_PER_LEAF / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(args.batch)
+        line = {
+            "metric": "leaf-evals/sec (policy+value, batched 9x9 positions)",
+            "value": value, "unit": "leaf-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={args.batch} 9x9 positions, PolicyNet logits+softmax and "
+                                   "ValueNet, device-resident inputs/outputs",
+                       "batch_per_gpu": args.batch, "weights": "policy_19 + value_synth (tests/golden)",
+                       "sharding": f"positions x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "bk_leaf_eval_kernel<3>", "kernel_ms": kern_ms,
+                         "algorithmic_flop_per_launch": args.batch * FLOP_PER_LEAF,
+                         "algorithmic_hbm_bytes_per_launch": args.batch * BYTES_PER_LEAF},
+            "cpu_baseline": cpu,
+            "host_buffer_e2e_leaf_evals_per_s": e2e,
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

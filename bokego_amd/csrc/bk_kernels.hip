@@ -23,6 +23,7 @@
 // resident).  BatchNorm (eval mode) is folded into the weights on the host in fp64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bk_internal.h"
 
@@ -288,15 +289,20 @@ hipError_t launch_nb(const bk_eval_args& a, int nets, hipStream_t stream) {
 
 }  // namespace
 
-// Picks boards-per-workgroup so that (rounds over the CUs) x (MFMA tiles per workgroup) is minimal.
+// Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is
+// (workgroup rounds over the CUs) x (32-row MFMA tiles per workgroup); NB=1 workgroups are small
+// enough (57 KB LDS) to sit two per CU but then share the pipes, so that buys nothing here.
 int bk_pick_nb(int B, int nets, int n_cu) {
+    if (const char* f = getenv("BK_FORCE_NB")) {
+        const int v = atoi(f);
+        if (v >= 1 && v <= 3) return v;
+    }
     const int mt[4] = {0, 3, 6, 8};
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
         const long wgs = (long)nets * ((B + nb - 1) / nb);
-        const long per_cu = nb == 1 ? 2 : 1;  // NB=1 fits two workgroups per CU (57 KB LDS each)
-        const long rounds = (wgs + n_cu * per_cu - 1) / (n_cu * per_cu);
+        const long rounds = (wgs + n_cu - 1) / n_cu;
         const long cost = rounds * mt[nb];
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }

@@ -43,7 +43,14 @@ def _lib():
         _LIB.bkref_policy_forward.restype = None
         _LIB.bkref_value_forward.argtypes = [pp, fp, ctypes.c_int, fp, fp]
         _LIB.bkref_value_forward.restype = None
+        _LIB.bkref_set_threads.argtypes = [ctypes.c_int]
+        _LIB.bkref_set_threads.restype = ctypes.c_int
     return _LIB
+
+
+def set_threads(n=0):
+    """Set (n>0) / query the OpenMP thread count used by the oracle."""
+    return _lib().bkref_set_threads(int(n))
 
 
 def _fp(a):

@@ -1,0 +1,98 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/bokego_amd.h declares, and fails
+loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+
+def _header_functions():
+    src = open(os.path.join(REPO, "include", "bokego_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bk_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(REPO, "bokego_amd", "libbokego_amd.so")):
+        g.build()
+    from bokego_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from bokego_amd import _lib
+    fns = _header_functions()
+    assert len(fns) >= 14
+    for f in fns:
+        assert hasattr(lib, f), f"{f} declared in include/bokego_amd.h but not exported"
+        assert f in _lib.SYMBOLS, f"{f} has no ctypes prototype in bokego_amd/_lib.py"
+    assert set(_lib.SYMBOLS) == set(fns)
+    assert lib.bk_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from bokego_amd import _lib
+    # 7*6 + 2 pointers in the trunk, +12 in the value head (include/bokego_amd.h)
+    assert ctypes.sizeof(_lib.TrunkWeights) == 44 * 8
+    assert ctypes.sizeof(_lib.ValueWeights) == 56 * 8
+    assert ctypes.sizeof(_lib.Stats) == 48
+
+
+def test_create_argument_errors(lib):
+    h = ctypes.c_void_p()
+    assert lib.bk_engine_create(None, None, 0, 16, ctypes.byref(h)) == -1      # BK_ERR_ARG
+    assert b"policy/value" in lib.bk_last_error(None)
+    from bokego_amd import _lib
+    pw = _lib.PolicyWeights()                                                  # all NULL pointers
+    assert lib.bk_engine_create(ctypes.byref(pw), None, 0, 16, ctypes.byref(h)) == -1
+    assert lib.bk_engine_create(ctypes.byref(pw), None, 0, 0, ctypes.byref(h)) == -1
+    assert lib.bk_engine_destroy(None) == -1
+    assert lib.bk_engine_max_batch(None) == -1
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """On a box without a GPU the engine must refuse to exist (BK_ERR_NO_GPU), not fall back."""
+    if lib.bk_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    with pytest.raises(RuntimeError, match="BK_ERR_NO_GPU"):
+        LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), None)
+
+
+def test_state_dict_validation(lib):
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    sd = load_bkw(os.path.join(GOLDEN, "policy_19.bkw"))
+    bad = dict(sd)
+    del bad["conv.9.weight"]
+    with pytest.raises(KeyError):
+        LeafEngine(bad, None)
+    bad = dict(sd)
+    bad["conv.0.weight"] = np.zeros((128, 27, 3, 3), np.float32)
+    with pytest.raises(ValueError):
+        LeafEngine(bad, None)
+    with pytest.raises(TypeError):
+        LeafEngine(None, None)
+
+
+def test_bkw_roundtrip(tmp_path):
+    import torch
+    from bokego_amd.bkw import load_bkw, save_bkw, state_dict_to_tensors, tensors_to_state_dict
+    sd = load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    assert sd["conv.0.weight"].shape == (128, 27, 5, 5) and sd["conv.21.bias"].shape == (1, 9, 9)
+    assert sd["lin1.weight"].shape == (64, 81) and sd["bn.running_var"].shape == (1,)
+    p = tmp_path / "x.bkw"
+    save_bkw(str(p), sd)
+    back = load_bkw(str(p))
+    assert list(back) == list(sd) and all(np.array_equal(back[k], sd[k]) for k in sd)
+    tsd = tensors_to_state_dict(sd)
+    assert "conv.1.num_batches_tracked" in tsd and tsd["conv.3.weight"].dtype == torch.float32
+    again = state_dict_to_tensors(tsd)
+    assert all(np.array_equal(again[k], sd[k]) for k in sd)
