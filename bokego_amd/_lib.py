@@ -58,6 +58,9 @@ SYMBOLS = {
     "bk_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "bk_submit": (ctypes.c_int64, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "bk_wait": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "bk_submit_prefix": (ctypes.c_int64, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
+    "bk_eval_device_prefix": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P,
+                                             _P, _P]),
     "bk_engine_set_profiling": (ctypes.c_int, [_P, ctypes.c_int]),
     "bk_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "bk_engine_max_batch": (ctypes.c_int, [_P]),

@@ -24,7 +24,7 @@ constexpr double kBnEps = 1e-5;  // torch.nn.BatchNorm default, nnet.py:33,98-99
 
 struct Slot {  // one in-flight host-buffer request
     int64_t ticket = 0;
-    int B = 0, want = 0;
+    int B = 0, n_policy = 0, want = 0;
     float *logits = nullptr, *probs = nullptr, *values = nullptr;  // caller's host buffers
     void* h_in = nullptr;                                          // pinned staging
     float *h_logits = nullptr, *h_probs = nullptr, *h_values = nullptr;
@@ -159,9 +159,10 @@ void free_slot(Slot& s) {
     s = Slot{};
 }
 
-int check_want(bk_engine* e, int B, int want) {
+int check_want(bk_engine* e, int B, int n_policy, int want) {
     if (!e) return BK_ERR_ARG;
     if (B < 0 || (want & ~7) || want == 0) return fail(e, BK_ERR_ARG, "bad B or want mask");
+    if (n_policy < 0 || n_policy > B) return fail(e, BK_ERR_ARG, "n_policy must be in [0, B]");
     if (B > e->max_batch) return fail(e, BK_ERR_BATCH, "B exceeds max_batch given at bk_engine_create");
     if ((want & (BK_WANT_LOGITS | BK_WANT_PROBS)) && !e->has_policy)
         return fail(e, BK_ERR_NO_NET, "policy outputs requested but the engine has no PolicyNet");
@@ -186,20 +187,21 @@ void drain_events(bk_engine* e) {
 }
 
 // enqueue one kernel launch on `stream`; all pointers are device pointers
-int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int want, float* d_logits, float* d_probs,
-            float* d_values, hipStream_t stream) {
+int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, int want, float* d_logits,
+            float* d_probs, float* d_values, hipStream_t stream) {
     if (B == 0) return BK_OK;
     bk_eval_args a{};
     a.net[0] = e->net[0];
     a.net[1] = e->net[1];
     a.feats = d_feats;
     a.feats_dtype = dtype;
-    a.B = B;
-    a.net_mask = ((want & (BK_WANT_LOGITS | BK_WANT_PROBS)) ? 1 : 0) | ((want & BK_WANT_VALUE) ? 2 : 0);
+    a.B_policy = (want & (BK_WANT_LOGITS | BK_WANT_PROBS)) ? n_policy : 0;
+    a.B_value = (want & BK_WANT_VALUE) ? B : 0;
     a.logits = (want & BK_WANT_LOGITS) ? d_logits : nullptr;
     a.probs = (want & BK_WANT_PROBS) ? d_probs : nullptr;
     a.values = (want & BK_WANT_VALUE) ? d_values : nullptr;
-    const int nb = bk_pick_nb(B, a.net_mask == 3 ? 2 : 1, e->n_cu);
+    if (a.B_policy + a.B_value == 0) return BK_OK;
+    const int nb = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
     bool timed = false;
     size_t slot = 0;
     if (e->profiling) {
@@ -331,9 +333,9 @@ int bk_engine_destroy(bk_engine* e) {
     return BK_OK;
 }
 
-int64_t bk_submit(bk_engine* e, const void* feats, int feats_dtype, int B, int want, float* logits, float* probs,
-                  float* values) {
-    int rc = check_want(e, B, want);
+int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B, int n_policy, int want,
+                         float* logits, float* probs, float* values) {
+    int rc = check_want(e, B, n_policy, want);
     if (rc) return rc;
     if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
     if (B > 0 && !feats) return fail(e, BK_ERR_ARG, "feats is NULL");
@@ -348,12 +350,12 @@ int64_t bk_submit(bk_engine* e, const void* feats, int feats_dtype, int B, int w
     if (B > 0) {
         std::memcpy(s->h_in, feats, (size_t)B * 2187 * esz);
         HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->stream));
-        rc = enqueue(e, s->d_in, feats_dtype, B, want, s->d_logits, s->d_probs, s->d_values, e->stream);
+        rc = enqueue(e, s->d_in, feats_dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream);
         if (rc) return rc;
-        if (want & BK_WANT_LOGITS)
-            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)B * 81 * 4, hipMemcpyDeviceToHost, e->stream));
-        if (want & BK_WANT_PROBS)
-            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)B * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+        if ((want & BK_WANT_LOGITS) && n_policy)
+            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+        if ((want & BK_WANT_PROBS) && n_policy)
+            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
         if (want & BK_WANT_VALUE)
             HIP_TRY(e, hipMemcpyAsync(s->h_values, s->d_values, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
     }
@@ -361,6 +363,7 @@ int64_t bk_submit(bk_engine* e, const void* feats, int feats_dtype, int B, int w
     s->busy = true;
     s->ticket = e->next_ticket++;
     s->B = B;
+    s->n_policy = n_policy;
     s->want = want;
     s->logits = logits;
     s->probs = probs;
@@ -373,13 +376,18 @@ int bk_wait(bk_engine* e, int64_t ticket) {
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
         HIP_TRY(e, hipEventSynchronize(s.done));
-        if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_logits, (size_t)s.B * 81 * 4);
-        if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_probs, (size_t)s.B * 81 * 4);
+        if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_logits, (size_t)s.n_policy * 81 * 4);
+        if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_probs, (size_t)s.n_policy * 81 * 4);
         if (s.want & BK_WANT_VALUE) std::memcpy(s.values, s.h_values, (size_t)s.B * 4);
         s.busy = false;
         return BK_OK;
     }
     return fail(e, BK_ERR_ARG, "unknown or already-waited ticket");
+}
+
+int64_t bk_submit(bk_engine* e, const void* feats, int feats_dtype, int B, int want, float* logits, float* probs,
+                  float* values) {
+    return bk_submit_prefix(e, feats, feats_dtype, B, B, want, logits, probs, values);
 }
 
 int bk_eval(bk_engine* e, const float* feats, int B, int want, float* logits, float* probs, float* values) {
@@ -396,7 +404,12 @@ int bk_eval_u8(bk_engine* e, const uint8_t* feats, int B, int want, float* logit
 
 int bk_eval_device(bk_engine* e, const void* d_feats, int feats_dtype, int B, int want, float* d_logits,
                    float* d_probs, float* d_values, void* stream) {
-    int rc = check_want(e, B, want);
+    return bk_eval_device_prefix(e, d_feats, feats_dtype, B, B, want, d_logits, d_probs, d_values, stream);
+}
+
+int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, int B, int n_policy, int want,
+                          float* d_logits, float* d_probs, float* d_values, void* stream) {
+    int rc = check_want(e, B, n_policy, want);
     if (rc) return rc;
     if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
     if (B > 0 && !d_feats) return fail(e, BK_ERR_ARG, "d_feats is NULL");
@@ -404,7 +417,7 @@ int bk_eval_device(bk_engine* e, const void* d_feats, int feats_dtype, int B, in
         ((want & BK_WANT_VALUE) && !d_values))
         return fail(e, BK_ERR_ARG, "an output requested in `want` has a NULL buffer");
     HIP_TRY(e, hipSetDevice(e->device));
-    return enqueue(e, d_feats, feats_dtype, B, want, d_logits, d_probs, d_values,
+    return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
                    stream ? static_cast<hipStream_t>(stream) : e->stream);
 }
 

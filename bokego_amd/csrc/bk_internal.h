@@ -30,13 +30,13 @@ struct bk_eval_args {
     bk_net_params net[2];  // [0] policy, [1] value
     const void* feats;     // [B][27][9][9] f32 or u8 (device)
     int feats_dtype;
-    int B;
-    int tasks;             // filled by the launcher
-    int net_mask;          // 1 policy, 2 value, 3 both
+    int B_policy;          // PolicyNet runs on positions [0, B_policy)   (0: not at all)
+    int B_value;           // ValueNet  runs on positions [0, B_value)
+    int tasks_p, tasks_v;  // filled by the launcher: ceil(B_x / NB)
     float* logits;         // [B][81] or null
     float* probs;          // [B][81] or null
     float* values;         // [B] or null
 };
 
-int bk_pick_nb(int B, int nets, int n_cu);
+int bk_pick_nb(int B_policy, int B_value, int n_cu);
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);

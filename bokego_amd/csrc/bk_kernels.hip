@@ -159,22 +159,24 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    // block -> (net, task).  With both nets, blocks b and b+8 share an XCD (round-robin
-    // dispatch): bit 2 of the block id picks the net, so each XCD's L2 streams ONE net's
-    // 3.9 MB of weights (speed only; any placement is correct).
+    // block -> (net, task).  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+    // while both nets have tasks left bit 2 of the block id picks the net: each XCD's 4 MB L2 then
+    // streams ONE net's 3.9 MB of weights.  The surplus tasks of the larger net follow linearly.
+    // (Speed only; any placement is correct.)
     int net, task;
     const int bid = blockIdx.x;
-    if (a.net_mask == 3) {
+    const int m4 = min(a.tasks_p, a.tasks_v) & ~3;
+    if (bid < 2 * m4) {
         net = (bid >> 2) & 1;
         task = ((bid >> 3) << 2) | (bid & 3);
     } else {
-        net = a.net_mask == 2 ? 1 : 0;
-        task = bid;
+        const int r = bid - 2 * m4;
+        if (r < a.tasks_p - m4) { net = 0; task = m4 + r; }
+        else { net = 1; task = m4 + r - (a.tasks_p - m4); }
     }
-    if (task >= a.tasks) return;
     const bk_net_params& P = a.net[net];
     const int b0 = task * NB;
-    const int nb = min(NB, a.B - b0);
+    const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
     for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
 }
 
 template <int NB>
-hipError_t launch_nb(const bk_eval_args& a, int nets, hipStream_t stream) {
+hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
     static bool attr_set = false;
     auto kern = bk_leaf_eval_kernel<NB>;
     if (!attr_set) {
@@ -281,8 +283,10 @@ hipError_t launch_nb(const bk_eval_args& a, int nets, hipStream_t stream) {
         attr_set = true;
     }
     bk_eval_args args = a;
-    args.tasks = (a.B + NB - 1) / NB;
-    const int grid = nets == 2 ? 8 * ((args.tasks + 3) / 4) : args.tasks;
+    args.tasks_p = (a.B_policy + NB - 1) / NB;
+    args.tasks_v = (a.B_value + NB - 1) / NB;
+    const int grid = args.tasks_p + args.tasks_v;
+    if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Geo<NB>::LDS_BYTES, stream, args);
     return hipGetLastError();
 }
@@ -292,7 +296,7 @@ hipError_t launch_nb(const bk_eval_args& a, int nets, hipStream_t stream) {
 // Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is
 // (workgroup rounds over the CUs) x (32-row MFMA tiles per workgroup); NB=1 workgroups are small
 // enough (57 KB LDS) to sit two per CU but then share the pipes, so that buys nothing here.
-int bk_pick_nb(int B, int nets, int n_cu) {
+int bk_pick_nb(int B_policy, int B_value, int n_cu) {
     if (const char* f = getenv("BK_FORCE_NB")) {
         const int v = atoi(f);
         if (v >= 1 && v <= 3) return v;
@@ -301,7 +305,7 @@ int bk_pick_nb(int B, int nets, int n_cu) {
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
-        const long wgs = (long)nets * ((B + nb - 1) / nb);
+        const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
         const long rounds = (wgs + n_cu - 1) / n_cu;
         const long cost = rounds * mt[nb];
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
@@ -310,10 +314,9 @@ int bk_pick_nb(int B, int nets, int n_cu) {
 }
 
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {
-    const int nets = a.net_mask == 3 ? 2 : 1;
     switch (nb) {
-        case 1: return launch_nb<1>(a, nets, stream);
-        case 2: return launch_nb<2>(a, nets, stream);
-        default: return launch_nb<3>(a, nets, stream);
+        case 1: return launch_nb<1>(a, stream);
+        case 2: return launch_nb<2>(a, stream);
+        default: return launch_nb<3>(a, stream);
     }
 }

@@ -127,20 +127,24 @@ class LeafEngine:
         return a, dt
 
     # -- host-buffer API -------------------------------------------------------------------
-    def submit(self, feats, logits=False, probs=True, value=True):
-        """Asynchronous evaluation of host features; returns a ticket for wait()."""
+    def submit(self, feats, logits=False, probs=True, value=True, n_policy=None):
+        """Asynchronous evaluation of host features; returns a ticket for wait().
+        n_policy: run the PolicyNet only on the first n_policy positions (MCTS expansion batches);
+        'logits'/'probs' then have n_policy rows, 'value' always B."""
         a, dt = self._feats(feats)
         B = a.shape[0]
+        npol = B if n_policy is None else int(n_policy)
         want = self._want(logits, probs, value)
         out = {}
         if logits:
-            out["logits"] = np.empty((B, 81), np.float32)
+            out["logits"] = np.empty((npol, 81), np.float32)
         if probs:
-            out["probs"] = np.empty((B, 81), np.float32)
+            out["probs"] = np.empty((npol, 81), np.float32)
         if value:
             out["value"] = np.empty((B,), np.float32)
         p = lambda k: out[k].ctypes.data if k in out else None  # noqa: E731
-        t = self._check(self._lib.bk_submit(self._h, a.ctypes.data, dt, B, want, p("logits"), p("probs"), p("value")))
+        t = self._check(self._lib.bk_submit_prefix(self._h, a.ctypes.data, dt, B, npol, want, p("logits"),
+                                                   p("probs"), p("value")))
         self._pending[t] = (a, out)
         return t
 
@@ -149,12 +153,12 @@ class LeafEngine:
         self._check(self._lib.bk_wait(self._h, ticket))
         return out
 
-    def eval(self, feats, logits=False, probs=True, value=True):
+    def eval(self, feats, logits=False, probs=True, value=True, n_policy=None):
         """Synchronous: dict with the requested 'logits' [B,81], 'probs' [B,81], 'value' [B]."""
-        return self.wait(self.submit(feats, logits=logits, probs=probs, value=value))
+        return self.wait(self.submit(feats, logits=logits, probs=probs, value=value, n_policy=n_policy))
 
     # -- device-resident API (torch CUDA/HIP tensors) -------------------------------------
-    def eval_device(self, d_feats, logits=False, probs=True, value=True, stream=None):
+    def eval_device(self, d_feats, logits=False, probs=True, value=True, stream=None, n_policy=None):
         """d_feats: torch tensor on this engine's GPU, float32 or uint8 [B,27,9,9].
         Runs on torch's current stream (or `stream`); returns dict of torch tensors."""
         import torch
@@ -173,17 +177,19 @@ class LeafEngine:
         if x.dim() != 4 or tuple(x.shape[1:]) != (27, 9, 9):
             raise ValueError(f"features must be [B,27,9,9], got {tuple(x.shape)}")
         B = x.shape[0]
+        npol = B if n_policy is None else int(n_policy)
         out = {}
         if logits:
-            out["logits"] = torch.empty((B, 81), dtype=torch.float32, device=x.device)
+            out["logits"] = torch.empty((npol, 81), dtype=torch.float32, device=x.device)
         if probs:
-            out["probs"] = torch.empty((B, 81), dtype=torch.float32, device=x.device)
+            out["probs"] = torch.empty((npol, 81), dtype=torch.float32, device=x.device)
         if value:
             out["value"] = torch.empty((B,), dtype=torch.float32, device=x.device)
         s = stream if stream is not None else torch.cuda.current_stream(x.device).cuda_stream
         p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
-        self._check(self._lib.bk_eval_device(self._h, x.data_ptr(), dt, B, self._want(logits, probs, value),
-                                             p("logits"), p("probs"), p("value"), ctypes.c_void_p(s)))
+        self._check(self._lib.bk_eval_device_prefix(self._h, x.data_ptr(), dt, B, npol,
+                                                    self._want(logits, probs, value), p("logits"), p("probs"),
+                                                    p("value"), ctypes.c_void_p(s)))
         out["_keepalive"] = x
         return out
 

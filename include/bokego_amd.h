@@ -127,6 +127,16 @@ int64_t bk_submit(bk_engine *e, const void *feats, int feats_dtype, int B, int w
                   float *values);
 int bk_wait(bk_engine *e, int64_t ticket);
 
+/*
+ * MCTS expansion batches (mcts.py:185-192 expands one node: ONE policy evaluation, mcts.py:371-383,
+ * but a value for every new child, mcts.py:393-403): PolicyNet outputs are produced only for the
+ * first n_policy positions (logits/probs buffers are [n_policy,81]), the value for all B.
+ */
+int64_t bk_submit_prefix(bk_engine *e, const void *feats, int feats_dtype, int B, int n_policy, int want,
+                         float *logits, float *probs, float *values);
+int bk_eval_device_prefix(bk_engine *e, const void *d_feats, int feats_dtype, int B, int n_policy, int want,
+                          float *d_logits, float *d_probs, float *d_values, void *stream);
+
 int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every kernel launch */
 int bk_stats(bk_engine *e, bk_stats_t *out);
 int bk_engine_max_batch(bk_engine *e);

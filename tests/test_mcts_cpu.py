@@ -1,0 +1,134 @@
+"""Host logic of the batched MCTS, on CPU: the product driver (bokego_amd/mcts.py) fed by the CPU
+oracle nets must reproduce (a) the search trace recorded from the reference itself and (b) the
+sequential restatement oracle/mcts_ref.py, move for move and visit for visit."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bokego_amd import go
+from bokego_amd.bkw import load_bkw
+from bokego_amd.mcts import MCTS, Go_MCTS
+from oracle.mcts_ref import RefMCTS
+from oracle.oracle import OraclePolicy, OracleValue
+
+from conftest import GOLDEN
+
+
+class _TorchWrap:
+    """the oracle nets behind the duck-typed interface MCTS expects of policy_net / value_net"""
+
+    def __init__(self, fn, value=False):
+        self.fn, self.value, self.calls, self.positions = fn, value, 0, 0
+
+    def to(self, device):
+        return self
+
+    def __call__(self, x):
+        self.calls += 1
+        self.positions += len(x)
+        out = self.fn(x.numpy())
+        return torch.from_numpy(out.reshape(-1, 1) if self.value else out)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    P = OraclePolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")))
+    V = OracleValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw")))
+    return P, V
+
+
+@pytest.fixture(scope="module")
+def trace():
+    return json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))
+
+
+def _play(tree, n_roll, n_moves):
+    out = []
+    for _ in range(n_moves):
+        tree.rollout(n_roll)
+        root = tree.root
+        kids = {c.mv: tree.N[c] for c in tree.children[root]}
+        rootN, wr = tree.N[root], tree.winrate()
+        best = tree.choose()
+        out.append({"move": best.last_move, "child_N": kids, "root_N": rootN, "root_winrate": wr})
+    return out
+
+
+def test_matches_reference_trace_r300(nets, trace):
+    """6 moves x 300 rollouts, expand_thresh=20: moves AND every root-child visit count equal the reference's."""
+    t = trace["r300_t20"]
+    torch.manual_seed(0)
+    pn, vn = _TorchWrap(nets[0]), _TorchWrap(nets[1], value=True)
+    tree = MCTS(Go_MCTS(), pn, vn, no_sim=True, **t["kwargs"])
+    got = _play(tree, t["rollouts"], len(t["moves"]))
+    for g, ref in zip(got, t["moves"]):
+        assert g["move"] == ref["move"]
+        assert g["child_N"] == {int(k): v for k, v in ref["child_N"].items()}
+        assert g["root_N"] == ref["root_N"]
+        assert abs(g["root_winrate"] - ref["root_winrate"]) < 1e-4
+    # batching really happened: far fewer network calls than positions
+    assert vn.positions > 3 * vn.calls
+
+
+def test_eager_equals_lazy_equals_sequential_restatement(nets):
+    P, V = nets
+    kw = dict(expand_thresh=15)
+    ref = RefMCTS(P, V, **kw)
+    eager = MCTS(Go_MCTS(), _TorchWrap(P), _TorchWrap(V, value=True), **kw)
+    lazy = MCTS(Go_MCTS(), _TorchWrap(P), _TorchWrap(V, value=True), eager_children=False, **kw)
+    for _ in range(4):
+        ref.rollout(200)
+        want = ref.child_visits()
+        for tree in (eager, lazy):
+            tree.rollout(200)
+            assert {c.mv: tree.N[c] for c in tree.children[tree.root]} == want
+        m = ref.choose()
+        assert eager.choose().last_move == m and lazy.choose().last_move == m
+    # lazy evaluates exactly what the sequential restatement evaluates; eager evaluates a superset
+    assert lazy.evaluator.n_positions - lazy.evaluator.n_policy <= ref.n_value_calls + ref.n_policy_calls
+    assert eager.evaluator.n_positions > lazy.evaluator.n_positions
+    assert eager.evaluator.n_batches < lazy.evaluator.n_batches
+
+
+def test_reference_api_surface(nets):
+    P, V = nets
+    with pytest.raises(TypeError):
+        MCTS(Go_MCTS())
+    with pytest.raises(TypeError):
+        MCTS(Go_MCTS(), _TorchWrap(P))                       # value_net required in no-sim mode
+    tree = MCTS(Go_MCTS(), _TorchWrap(P), _TorchWrap(V, value=True), expand_thresh=5)
+    root = tree.root
+    assert root in tree.children and len(tree.children[root]) == 81
+    assert tree.N[root] == 0 and tree.winrate() == 0
+    tree.rollout(50)
+    assert tree.N[root] == 50 and sum(tree.N[c] for c in tree.children[root]) == 50
+    assert 0.0 < tree.winrate() < 1.0 and root.winrate == tree.winrate()
+    d = root.dist
+    assert abs(d.probs.sum().item() - 1) < 1e-5 and d.probs.argmax().item() == 40
+    assert isinstance(root.value, float) and root.features.shape == (27, 9, 9)
+    analyze = {}
+    tree.rollout(100, analyze_dict=analyze)
+    assert analyze and all(v[0] is k for k, v in analyze.items())
+    child = tree.choose()
+    assert tree.root is child and child.turn == 1 and child in tree.children
+    # a position reached by transposition shares statistics: equal nodes are one entry
+    twin = Go_MCTS(board=child.board, ko=child.ko, turn=child.turn, last_move=child.last_move)
+    assert tree.N[twin] == tree.N[child] > 0
+    assert Go_MCTS().dist is None and Go_MCTS().value is None  # no tree attached (mcts.py:373-374)
+    # terminal nodes: two passes
+    t = child.make_move(go.PASS)
+    assert t._terminal and t.find_children() == []
+
+
+def test_noise_and_branching(nets):
+    P, V = nets
+    torch.manual_seed(3)
+    tree = MCTS(Go_MCTS(), _TorchWrap(P), _TorchWrap(V, value=True), noise_weight=0.25, branch_num=5, expand_thresh=3)
+    assert len(tree.children[tree.root]) == 5
+    p = tree.root.dist.probs
+    assert abs(p.sum().item() - 1) < 1e-4 and p[40] < 0.82     # noise moved mass away from the 0.8186 top move
+    tree.rollout(40)
+    assert tree.N[tree.root] == 40
