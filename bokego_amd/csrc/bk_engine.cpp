@@ -417,8 +417,10 @@ int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, in
         ((want & BK_WANT_VALUE) && !d_values))
         return fail(e, BK_ERR_ARG, "an output requested in `want` has a NULL buffer");
     HIP_TRY(e, hipSetDevice(e->device));
+    // `stream` is used as given: NULL is HIP's null (legacy default) stream, which is also what
+    // torch.cuda.current_stream() is unless the caller switched streams.
     return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
-                   stream ? static_cast<hipStream_t>(stream) : e->stream);
+                   static_cast<hipStream_t>(stream));
 }
 
 int bk_engine_set_profiling(bk_engine* e, int on) {

@@ -112,7 +112,8 @@ int bk_eval_u8(bk_engine *e, const uint8_t *feats, int B, int want, float *logit
 /*
  * Device-resident variant (the reference's `--gpu` path keeps tensors on the device,
  * nnet.py:272 `.to(device)`): all pointers are device pointers on the engine's device.
- * `stream` is a hipStream_t (NULL = the engine's own stream).  Asynchronous on that stream.
+ * `stream` is the hipStream_t to launch on (NULL = HIP's null stream, i.e. torch's default
+ * current stream).  Asynchronous on that stream; the caller orders its own reads after it.
  */
 int bk_eval_device(bk_engine *e, const void *d_feats, int feats_dtype, int B, int want, float *d_logits,
                    float *d_probs, float *d_values, void *stream);

@@ -1,0 +1,101 @@
+"""-m gpu: drop-in nets + batched MCTS on the HIP engine (BASELINE configs 1 and 3)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from bokego_amd.bkw import load_bkw
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sds():
+    return load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return (np.load(os.path.join(GOLDEN, "features.npz"))["incremental"].astype(np.float32),
+            np.load(os.path.join(GOLDEN, "nets.npz")))
+
+
+def test_policy_prefix_split(sds, gold):
+    from bokego_amd.engine import LeafEngine
+    f, n = gold
+    e = LeafEngine(sds[0], sds[1], max_batch=600)
+    full = e.eval(f, logits=True, probs=True, value=True)
+    for k in (0, 1, 2, 5, 13, 100, 536):
+        o = e.eval(f, logits=True, probs=True, value=True, n_policy=k)
+        assert o["logits"].shape == (k, 81) and o["value"].shape == (536,)
+        assert np.array_equal(o["logits"], full["logits"][:k]) and np.array_equal(o["probs"], full["probs"][:k])
+        assert np.array_equal(o["value"], full["value"])
+    o = e.eval(f[:7], logits=False, probs=True, value=False, n_policy=3)
+    assert np.array_equal(o["probs"], full["probs"][:3]) and "value" not in o
+    with pytest.raises(ValueError):
+        e.eval(f[:7], n_policy=8)
+    e.close()
+
+
+def test_dropin_nets_reference_surface(sds, gold):
+    """What boke.py:30-38 and nnet.py:265-297 do with the nets, on the HIP shims."""
+    from bokego_amd import go, nnet
+    f, n = gold
+    pi = nnet.HipPolicyNet()
+    with pytest.raises(RuntimeError):
+        pi(torch.zeros(1, 27, 9, 9))                         # no weights yet
+    pi.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
+    assert pi.eval() is pi and pi.to(torch.device("cpu")) is pi
+    val = nnet.HipValueNet()
+    val.load_state_dict(sds[1])
+    x = torch.from_numpy(f[:9])
+    lg, v = pi(x), val(x)
+    assert lg.shape == (9, 81) and v.shape == (9, 1) and lg.dtype == torch.float32
+    assert np.abs(lg.numpy() - n["logits_b1"][:9]).max() < 1e-4
+    assert np.abs(v.numpy().reshape(-1) - n["values_b1"][:9]).max() < 1e-4
+    # cuda tensors in -> cuda tensors out
+    assert pi(x.cuda()).is_cuda and np.abs(pi(x.cuda()).cpu().numpy() - lg.numpy()).max() == 0
+    g = go.Game()
+    d = nnet.policy_dist(pi, g)
+    assert abs(d.probs[40].item() - 0.818645) < 1e-5 and d.probs.argmax().item() == 40   # SURVEY 8c known answer
+    assert abs(nnet.value(val, g) - float(n["values_b1"][0])) < 1e-4
+    torch.manual_seed(0)
+    assert 0 <= nnet.policy_sample(pi, g).item() < 81
+    # ValueNet.load_policy_dict overlays a policy trunk (nnet.py:103-107)
+    v2 = nnet.HipValueNet(sds[1])
+    v2.load_policy_dict(pi.state_dict())
+    assert np.array_equal(v2.state_dict()["conv.3.weight"].numpy(), sds[0]["conv.3.weight"])
+    assert abs(v2(x)[0, 0].item() - v[0, 0].item()) > 1e-6
+    eng = nnet.fuse(pi, val)
+    assert pi.engine() is eng and val.engine() is eng
+    assert np.abs(pi(x).numpy() - lg.numpy()).max() == 0
+
+
+def test_config3_genmove_1600_rollouts_matches_reference(sds):
+    """BASELINE config 3: 1600 rollouts/move, batched leaf queue, 1 GPU: same moves and the same
+    root-child visit counts as the trace recorded from the reference (tests/golden/mcts_trace.json)."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts import MCTS, Go_MCTS
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))["r1600"]
+    pi, val = nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1])
+    torch.manual_seed(0)
+    tree = MCTS(Go_MCTS(), pi, val, no_sim=True)
+    t0 = time.time()
+    for ref in t["moves"]:
+        tree.rollout(t["rollouts"])
+        kids = {c.mv: tree.N[c] for c in tree.children[tree.root]}
+        rootN = tree.N[tree.root]
+        best = tree.choose()
+        assert best.last_move == ref["move"], (best.last_move, ref["alpha"])
+        assert kids == {int(k): v for k, v in ref["child_N"].items()}
+        assert rootN == ref["root_N"]
+    dt = (time.time() - t0) / len(t["moves"])
+    ev = tree.evaluator
+    print(f"\nconfig3: {dt*1e3:.0f} ms/move, {ev.n_positions/len(t['moves']):.0f} evals/move, "
+          f"mean batch {ev.n_positions/ev.n_batches:.1f}, reference evals: {t['n_value_evals']} value / {t['n_policy_evals']} policy")
+    assert ev.n_positions / ev.n_batches > 20
