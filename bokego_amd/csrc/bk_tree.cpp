@@ -1,0 +1,473 @@
+// bk_tree.cpp -- native PUCT search core and lock-step game pool (host only, part of libbkgo.so).
+//
+// Same search as the reference's bokego/mcts.py:110-234 (and as bokego_amd/mcts.py, against which
+// tests compare it visit for visit): PUCT selection  -avg + c*P(move)*sqrt(sum N)/(1+N), a leaf is
+// expanded on the visit after N > expand_thresh, the value of the last node of the path is backed
+// up with alternating sign, the most visited child is chosen and becomes the new root with its
+// subtree kept.  Positions equal in (board, ko, last move, side) share one node (the reference's
+// dicts are keyed that way, mcts.py:294-299).
+//
+// A pool advances many independent games; each game runs until it needs network outputs, the
+// pool gathers every game's request into ONE batch of feature planes (policy positions first),
+// the caller evaluates it on the GPU and hands the results back.  Nothing here touches HIP.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bokego_go.h"
+#include "../../include/bokego_tree.h"
+
+namespace {
+
+struct TNode {
+    bk_pos pos;
+    double V = 0.0;
+    int N = 0;
+    float value = 0.f;
+    uint8_t has_value = 0, has_prior = 0, expanded = 0, terminal = 0;
+    int kids_off = 0, n_kids = 0;
+    int prior_off = -1;
+    int mv = BK_NO_MOVE;
+};
+
+enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_WAIT_LEAF, S_CHOOSE, S_DONE };
+
+struct Rng {  // xoshiro256** seeded by splitmix64: per-game stream, independent of how games are sharded
+    uint64_t s[4];
+    explicit Rng(uint64_t seed) {
+        uint64_t x = seed;
+        for (auto& v : s) {
+            uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            v = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    double normal() {
+        double u, v, q;
+        do { u = 2 * uniform() - 1; v = 2 * uniform() - 1; q = u * u + v * v; } while (q >= 1 || q == 0);
+        return u * std::sqrt(-2 * std::log(q) / q);
+    }
+    double gamma(double a) {  // Marsaglia-Tsang; a < 1 via the U^(1/a) boost
+        if (a < 1) return gamma(a + 1) * std::pow(uniform(), 1.0 / a);
+        const double d = a - 1.0 / 3, c = 1 / std::sqrt(9 * d);
+        for (;;) {
+            double x, v;
+            do { x = normal(); v = 1 + c * x; } while (v <= 0);
+            v = v * v * v;
+            const double u = uniform();
+            if (u < 1 - 0.0331 * x * x * x * x || std::log(u) < 0.5 * x * x + d * (1 - v + std::log(v))) return d * v;
+        }
+    }
+};
+
+struct Game {
+    bk_search_params prm;
+    std::vector<TNode> nodes;
+    std::vector<int> kid_ids;
+    std::vector<double> priors;
+    std::unordered_map<uint64_t, std::vector<int>> table;
+    int root = -1;
+    State state = S_INIT;
+    int remaining = 0;
+    std::vector<int> path;
+    std::vector<int> req_policy, req_value;
+    Rng rng;
+    std::vector<int16_t> moves;
+    std::vector<std::vector<std::pair<int16_t, int32_t>>> visit_log;  // per ply: (move, N) of the root's children
+    uint64_t n_value_evals = 0, n_policy_evals = 0, n_requests = 0;
+    float final_score = 0.f;
+
+    Game(const bk_search_params& p, uint64_t seed) : prm(p), rng(seed) {}
+
+    static uint64_t key_hash(const bk_pos& p) { return p.hash ^ (0x9E3779B97F4A7C15ull * (uint64_t)(uint16_t)p.last_move); }
+    static bool same(const bk_pos& a, const bk_pos& b) {
+        return a.ko == b.ko && a.last_move == b.last_move && ((a.turn ^ b.turn) & 1) == 0 &&
+               std::memcmp(a.board, b.board, 81) == 0;
+    }
+    int intern(const bk_pos& p) {
+        auto& bucket = table[key_hash(p)];
+        for (int id : bucket)
+            if (same(nodes[id].pos, p)) return id;
+        TNode n;
+        n.pos = p;
+        n.mv = p.last_move;
+        n.terminal = (p.turn > prm.max_turns || p.last_move == BK_PASS) ? 1 : 0;  // mcts.py:362-364
+        nodes.push_back(n);
+        bucket.push_back((int)nodes.size() - 1);
+        return (int)nodes.size() - 1;
+    }
+
+    // mcts.py:185-192 + the eager evaluation of the new children
+    void expand(int id) {
+        if (nodes[id].expanded) return;
+        bk_pos kids[81];
+        int16_t mv[81];
+        int n = 0;
+        if (!nodes[id].terminal) n = bk_pos_children(&nodes[id].pos, kids, mv);
+        const int off = (int)kid_ids.size();
+        for (int i = 0; i < n; ++i) kid_ids.push_back(intern(kids[i]));  // may reallocate `nodes`
+        TNode& nd = nodes[id];
+        nd.kids_off = off;
+        nd.n_kids = n;
+        nd.expanded = 1;
+        if (!nd.has_prior) req_policy.push_back(id);
+        if (prm.eager)
+            for (int i = 0; i < n; ++i) {
+                const int c = kid_ids[off + i];
+                if (!nodes[c].has_value && std::find(req_value.begin(), req_value.end(), c) == req_value.end())
+                    req_value.push_back(c);
+            }
+    }
+
+    int select(int id) const {  // mcts.py:219-234
+        const TNode& nd = nodes[id];
+        const int* kids = &kid_ids[nd.kids_off];
+        long total = 0;
+        for (int i = 0; i < nd.n_kids; ++i) total += nodes[kids[i]].N;
+        if (total == 0) total = 1;
+        const double sq = std::sqrt((double)total), c = prm.c_puct;
+        const double* prior = &priors[nd.prior_off];
+        int best = -1;
+        double best_s = 0;
+        for (int i = 0; i < nd.n_kids; ++i) {
+            const TNode& k = nodes[kids[i]];
+            const double avg = k.N == 0 ? 0.0 : k.V / (double)k.N;
+            const double s = -avg + (c * prior[k.mv] * sq / (double)(1 + k.N));
+            if (best < 0 || s > best_s) { best = kids[i]; best_s = s; }
+        }
+        return best;
+    }
+
+    void backprop() {  // mcts.py:208-217
+        double v = (double)nodes[path.back()].value;
+        for (int i = (int)path.size() - 1; i >= 0; --i) {
+            nodes[path[i]].N += 1;
+            nodes[path[i]].V += v;
+            v = -v;
+        }
+    }
+
+    void add_noise(int id) {  // mcts.py:366-369 with a per-game generator
+        if (prm.noise_weight <= 0.f) return;
+        double g[81], sum = 0;
+        for (auto& x : g) { x = rng.gamma(0.1); sum += x; }
+        double* p = &priors[nodes[id].prior_off];
+        const float w = prm.noise_weight;
+        for (int i = 0; i < 81; ++i) p[i] = (double)((1.f - w) * (float)p[i] + w * (float)(g[i] / sum));
+    }
+
+    int pick_move() {  // most visited child, lowest move index on ties (mcts.py:122-128); early plies sampled
+        const TNode& r = nodes[root];
+        const int* kids = &kid_ids[r.kids_off];
+        if ((int)moves.size() < prm.sample_plies) {
+            long tot = 0;
+            for (int i = 0; i < r.n_kids; ++i) tot += nodes[kids[i]].N;
+            if (tot > 0) {
+                long t = (long)(rng.uniform() * (double)tot);
+                for (int i = 0; i < r.n_kids; ++i) {
+                    t -= nodes[kids[i]].N;
+                    if (t < 0) return kids[i];
+                }
+            }
+        }
+        int best = -1, best_n = -1;
+        for (int i = 0; i < r.n_kids; ++i)
+            if (nodes[kids[i]].N > best_n) { best = kids[i]; best_n = nodes[kids[i]].N; }
+        return best;
+    }
+
+    void prune() {  // keep only the new root's subtree (bounds memory over a whole game)
+        std::vector<int> remap(nodes.size(), -1), order;
+        order.push_back(root);
+        remap[root] = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const TNode& n = nodes[order[i]];
+            for (int k = 0; k < n.n_kids; ++k) {
+                const int c = kid_ids[n.kids_off + k];
+                if (remap[c] < 0) { remap[c] = (int)order.size(); order.push_back(c); }
+            }
+        }
+        std::vector<TNode> nn;
+        std::vector<int> nk;
+        std::vector<double> np;
+        nn.reserve(order.size());
+        for (int old : order) {
+            TNode n = nodes[old];
+            const int off = (int)nk.size();
+            for (int k = 0; k < n.n_kids; ++k) nk.push_back(remap[kid_ids[n.kids_off + k]]);
+            n.kids_off = off;
+            if (n.has_prior) {
+                const int po = (int)np.size();
+                np.insert(np.end(), priors.begin() + n.prior_off, priors.begin() + n.prior_off + 81);
+                n.prior_off = po;
+            }
+            nn.push_back(n);
+        }
+        nodes.swap(nn);
+        kid_ids.swap(nk);
+        priors.swap(np);
+        table.clear();
+        for (int i = 0; i < (int)nodes.size(); ++i) table[key_hash(nodes[i].pos)].push_back(i);
+        root = 0;
+    }
+
+    bool has_request() const { return !req_policy.empty() || !req_value.empty(); }
+
+    // run until network outputs are needed (returns true) or the game is over (false)
+    bool advance() {
+        for (;;) {
+            switch (state) {
+                case S_INIT: {
+                    bk_pos p;
+                    bk_pos_init(&p);
+                    root = intern(p);
+                    state = S_ROOT_EXPAND;
+                    break;
+                }
+                case S_ROOT_EXPAND:
+                    expand(root);
+                    if (!nodes[root].has_prior && req_policy.empty()) req_policy.push_back(root);
+                    state = S_WAIT_ROOT;
+                    if (has_request()) return true;
+                    break;
+                case S_WAIT_ROOT:
+                    state = S_ROOT_READY;
+                    break;
+                case S_ROOT_READY:
+                    add_noise(root);
+                    if (nodes[root].terminal || nodes[root].n_kids == 0) {
+                        final_score = bk_pos_score(&nodes[root].pos, prm.komi);
+                        state = S_DONE;
+                        break;
+                    }
+                    remaining = prm.rollouts;
+                    state = S_SEARCH;
+                    break;
+                case S_SEARCH: {
+                    bool waiting = false;
+                    while (remaining > 0) {
+                        path.clear();
+                        int id = root;
+                        path.push_back(id);
+                        for (;;) {  // mcts.py:172-183
+                            if (nodes[id].n_kids == 0) {
+                                if (!nodes[id].expanded && nodes[id].N > prm.expand_thresh) expand(id);
+                                break;
+                            }
+                            id = select(id);
+                            path.push_back(id);
+                        }
+                        if (!nodes[path.back()].has_value &&
+                            std::find(req_value.begin(), req_value.end(), path.back()) == req_value.end())
+                            req_value.push_back(path.back());
+                        if (has_request()) { waiting = true; break; }
+                        backprop();
+                        --remaining;
+                    }
+                    if (waiting) { state = S_WAIT_LEAF; return true; }
+                    state = S_CHOOSE;
+                    break;
+                }
+                case S_WAIT_LEAF:
+                    backprop();
+                    --remaining;
+                    state = S_SEARCH;
+                    break;
+                case S_CHOOSE: {
+                    const int best = pick_move();
+                    if (prm.record_visits) {
+                        visit_log.emplace_back();
+                        const TNode& r = nodes[root];
+                        for (int i = 0; i < r.n_kids; ++i) {
+                            const TNode& k = nodes[kid_ids[r.kids_off + i]];
+                            visit_log.back().emplace_back((int16_t)k.mv, (int32_t)k.N);
+                        }
+                    }
+                    moves.push_back((int16_t)nodes[best].mv);
+                    root = best;
+                    if (prm.prune) prune();
+                    state = S_ROOT_EXPAND;
+                    break;
+                }
+                case S_DONE:
+                    return false;
+            }
+        }
+    }
+
+    void deliver_policy(int id, const float* probs) {
+        TNode& n = nodes[id];
+        if (!n.has_prior) {
+            n.prior_off = (int)priors.size();
+            for (int i = 0; i < 81; ++i) priors.push_back((double)probs[i]);
+            n.has_prior = 1;
+            ++n_policy_evals;
+        }
+    }
+    void deliver_value(int id, float v) {
+        TNode& n = nodes[id];
+        if (!n.has_value) { n.value = v; n.has_value = 1; ++n_value_evals; }
+    }
+};
+
+}  // namespace
+
+struct bk_pool {
+    std::vector<Game> games;
+    std::vector<int> active;      // games included in the last collect, in batch order
+    std::vector<int> pol_off, val_off;
+    int threads = 1;
+};
+
+extern "C" {
+
+void bk_search_params_default(bk_search_params* p) {
+    p->rollouts = 400;
+    p->expand_thresh = 100;
+    p->c_puct = 4.0;
+    p->noise_weight = 0.f;
+    p->sample_plies = 0;
+    p->max_turns = 80;
+    p->eager = 1;
+    p->komi = 5.5f;
+    p->record_visits = 0;
+    p->prune = 0;
+}
+
+bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {
+    if (n_games <= 0 || !prm || !seeds) return nullptr;
+    bk_pool* p = new bk_pool();
+    p->games.reserve(n_games);
+    for (int i = 0; i < n_games; ++i) p->games.emplace_back(*prm, seeds[i]);
+    p->threads = threads > 0 ? threads : 1;
+    return p;
+}
+
+void bk_pool_destroy(bk_pool* p) { delete p; }
+
+int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
+    const int G = (int)p->games.size();
+    std::vector<char> wants(G, 0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
+    for (int g = 0; g < G; ++g) {
+        Game& gm = p->games[g];
+        if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
+        else if (gm.has_request()) wants[g] = 1;
+    }
+    // batch layout: [policy nodes of every game ...][value nodes of every game ...]; games whose
+    // request does not fit under `cap` keep it for the next collect
+    p->active.clear();
+    p->pol_off.clear();
+    p->val_off.clear();
+    int npol = 0, nval = 0;
+    for (int g = 0; g < G; ++g) {
+        if (!wants[g]) continue;
+        Game& gm = p->games[g];
+        const int need = (int)(gm.req_policy.size() + gm.req_value.size());
+        if (npol + nval + need > cap) continue;
+        p->active.push_back(g);
+        p->pol_off.push_back(npol);
+        p->val_off.push_back(nval);
+        npol += (int)gm.req_policy.size();
+        nval += (int)gm.req_value.size();
+    }
+    const int A = (int)p->active.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
+    for (int a = 0; a < A; ++a) {
+        Game& gm = p->games[p->active[a]];
+        for (size_t i = 0; i < gm.req_policy.size(); ++i)
+            bk_pos_features_u8(&gm.nodes[gm.req_policy[i]].pos, feats + (size_t)(p->pol_off[a] + i) * 2187, 0);
+        for (size_t i = 0; i < gm.req_value.size(); ++i)
+            bk_pos_features_u8(&gm.nodes[gm.req_value[i]].pos, feats + (size_t)(npol + p->val_off[a] + i) * 2187, 0);
+        gm.n_requests += 1;
+    }
+    *n_policy = npol;
+    return npol + nval;
+}
+
+void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
+    int npol = 0;
+    for (size_t a = 0; a < p->active.size(); ++a) npol += (int)p->games[p->active[a]].req_policy.size();
+    const int A = (int)p->active.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
+    for (int a = 0; a < A; ++a) {
+        Game& gm = p->games[p->active[a]];
+        for (size_t i = 0; i < gm.req_policy.size(); ++i) {
+            const int row = p->pol_off[a] + (int)i;
+            gm.deliver_policy(gm.req_policy[i], probs + (size_t)row * 81);
+            if (values) gm.deliver_value(gm.req_policy[i], values[row]);
+        }
+        for (size_t i = 0; i < gm.req_value.size(); ++i) gm.deliver_value(gm.req_value[i], values[npol + p->val_off[a] + (int)i]);
+        gm.req_policy.clear();
+        gm.req_value.clear();
+    }
+    p->active.clear();
+}
+
+int bk_pool_n_games(const bk_pool* p) { return (int)p->games.size(); }
+
+int bk_pool_n_done(const bk_pool* p) {
+    int n = 0;
+    for (const auto& g : p->games) n += g.state == S_DONE;
+    return n;
+}
+
+int bk_pool_game_info(const bk_pool* p, int g, bk_game_info* out) {
+    if (g < 0 || g >= (int)p->games.size() || !out) return -1;
+    const Game& gm = p->games[g];
+    out->done = gm.state == S_DONE;
+    out->n_moves = (int)gm.moves.size();
+    out->score = gm.final_score;
+    out->n_value_evals = gm.n_value_evals;
+    out->n_policy_evals = gm.n_policy_evals;
+    out->n_requests = gm.n_requests;
+    out->n_nodes = (int)gm.nodes.size();
+    out->root_N = gm.root >= 0 ? gm.nodes[gm.root].N : 0;
+    out->root_V = gm.root >= 0 ? gm.nodes[gm.root].V : 0.0;
+    return 0;
+}
+
+int bk_pool_game_moves(const bk_pool* p, int g, int16_t* out, int cap) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const auto& m = p->games[g].moves;
+    const int n = std::min((int)m.size(), cap);
+    std::memcpy(out, m.data(), (size_t)n * sizeof(int16_t));
+    return (int)m.size();
+}
+
+int bk_pool_game_visits(const bk_pool* p, int g, int ply, int16_t* moves, int32_t* N) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const auto& log = p->games[g].visit_log;
+    if (ply < 0 || ply >= (int)log.size()) return -1;
+    for (size_t i = 0; i < log[ply].size(); ++i) {
+        moves[i] = log[ply][i].first;
+        N[i] = log[ply][i].second;
+    }
+    return (int)log[ply].size();
+}
+
+int bk_pool_root_children(const bk_pool* p, int g, int16_t* moves, int32_t* N, double* V) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    if (gm.root < 0) return 0;
+    const TNode& r = gm.nodes[gm.root];
+    for (int i = 0; i < r.n_kids; ++i) {
+        const TNode& k = gm.nodes[gm.kid_ids[r.kids_off + i]];
+        moves[i] = (int16_t)k.mv;
+        N[i] = k.N;
+        V[i] = k.V;
+    }
+    return r.n_kids;
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+"""Self-play with MCTS on many concurrent games, sharded over GPUs (BASELINE config 4).
+
+The reference's bin/selfplay.py plays raw policy-vs-policy games in `cpu_count()` processes with
+shared CPU tensors (selfplay.py:18-57,177-199) and never uses MCTS; config 4 composes its game
+loop with `MCTS`.  Here:
+
+  * every rank (one process per GPU) owns the games `gid % world == rank`; a game's randomness
+    comes only from `seed_base + gid`, so the set of games does not depend on the world size;
+  * a rank's games live in native lock-step pools (include/bokego_tree.h): each step gathers the
+    pending leaf evaluations of ALL its games into one batch for the HIP engine; two pools
+    alternate so the host advances one while the GPU evaluates the other;
+  * there is no data-path collective.  At the end of the generation ONE all-reduce (RCCL over
+    xGMI on GPUs, gloo in the CPU tests) sums a small statistics vector.
+"""
+import argparse
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+
+from . import go
+
+# ---- ctypes view of include/bokego_tree.h ------------------------------------------------------------
+
+
+class SearchParams(ctypes.Structure):
+    _fields_ = [("rollouts", ctypes.c_int32), ("expand_thresh", ctypes.c_int32), ("c_puct", ctypes.c_double),
+                ("noise_weight", ctypes.c_float), ("sample_plies", ctypes.c_int32), ("max_turns", ctypes.c_int32),
+                ("eager", ctypes.c_int32), ("komi", ctypes.c_float), ("record_visits", ctypes.c_int32),
+                ("prune", ctypes.c_int32)]
+
+
+class GameInfo(ctypes.Structure):
+    _fields_ = [("done", ctypes.c_int32), ("n_moves", ctypes.c_int32), ("score", ctypes.c_float),
+                ("n_nodes", ctypes.c_int32), ("n_value_evals", ctypes.c_uint64), ("n_policy_evals", ctypes.c_uint64),
+                ("n_requests", ctypes.c_uint64), ("root_N", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("root_V", ctypes.c_double)]
+
+
+_VP = ctypes.c_void_p
+TREE_SYMBOLS = {
+    "bk_search_params_default": (None, [ctypes.POINTER(SearchParams)]),
+    "bk_pool_create": (_VP, [ctypes.c_int, ctypes.POINTER(SearchParams), _VP, ctypes.c_int]),
+    "bk_pool_destroy": (None, [_VP]),
+    "bk_pool_collect": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "bk_pool_deliver": (None, [_VP, _VP, _VP]),
+    "bk_pool_n_games": (ctypes.c_int, [_VP]),
+    "bk_pool_n_done": (ctypes.c_int, [_VP]),
+    "bk_pool_game_info": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(GameInfo)]),
+    "bk_pool_game_moves": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int]),
+    "bk_pool_root_children": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, _VP]),
+    "bk_pool_game_visits": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
+}
+_tree_ready = False
+
+
+def treelib():
+    global _tree_ready
+    lib = go.golib()
+    if not _tree_ready:
+        for name, (res, args) in TREE_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _tree_ready = True
+    return lib
+
+
+def search_params(**kw):
+    p = SearchParams()
+    treelib().bk_search_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown search parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+class GamePool:
+    """Lock-step pool of independent self-play games on the native tree core."""
+
+    def __init__(self, seeds, params, cap=4096, threads=None):
+        self._lib = treelib()
+        self.seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        self.n = len(self.seeds)
+        self.cap = max(int(cap), 82)
+        threads = threads or max(1, min(16, len(os.sched_getaffinity(0))))
+        self._h = self._lib.bk_pool_create(self.n, ctypes.byref(params), self.seeds.ctypes.data, int(threads))
+        if not self._h:
+            raise RuntimeError("bk_pool_create failed")
+        self._feats = np.empty((self.cap, 27, 9, 9), np.uint8)
+
+    def close(self):
+        if self._h:
+            self._lib.bk_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def collect(self):
+        """-> (uint8 feats [B,27,9,9] view, n_policy); B == 0 when every game is finished."""
+        npol = ctypes.c_int(0)
+        B = self._lib.bk_pool_collect(self._h, self._feats.ctypes.data, self.cap, ctypes.byref(npol))
+        return self._feats[:B], npol.value
+
+    def deliver(self, probs, values):
+        probs = np.ascontiguousarray(probs, dtype=np.float32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        self._lib.bk_pool_deliver(self._h, probs.ctypes.data, values.ctypes.data)
+
+    @property
+    def n_done(self):
+        return self._lib.bk_pool_n_done(self._h)
+
+    def info(self, g):
+        gi = GameInfo()
+        self._lib.bk_pool_game_info(self._h, g, ctypes.byref(gi))
+        return {f: getattr(gi, f) for f, _ in GameInfo._fields_ if f != "reserved"}
+
+    def moves(self, g):
+        buf = np.empty(128, np.int16)
+        n = self._lib.bk_pool_game_moves(self._h, g, buf.ctypes.data, 128)
+        return buf[:n].tolist()
+
+    def visits(self, g, ply):
+        """{move: N} of the root's children when `ply` was chosen (search_params(record_visits=1))."""
+        mv, N = np.empty(81, np.int16), np.empty(81, np.int32)
+        n = self._lib.bk_pool_game_visits(self._h, g, ply, mv.ctypes.data, N.ctypes.data)
+        if n < 0:
+            raise IndexError("no visit record for that ply (record_visits off?)")
+        return {int(mv[i]): int(N[i]) for i in range(n)}
+
+    def root_children(self, g):
+        mv, N, V = np.empty(81, np.int16), np.empty(81, np.int32), np.empty(81, np.float64)
+        n = self._lib.bk_pool_root_children(self._h, g, mv.ctypes.data, N.ctypes.data, V.ctypes.data)
+        return {int(mv[i]): (int(N[i]), float(V[i])) for i in range(n)}
+
+
+def normalise_like_categorical(probs):
+    """torch's Categorical(probs) divides by the row sum (reference nnet.py:274)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(probs, dtype=np.float32))
+    return (t / t.sum(-1, keepdim=True)).numpy()
+
+
+class EngineEvaluator:
+    """feats -> (probs, values) on a LeafEngine, synchronous or split into submit/finish."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.positions = self.batches = 0
+
+    def submit(self, feats, n_policy):
+        self.positions += len(feats)
+        self.batches += 1
+        return self.engine.submit(feats, logits=False, probs=n_policy > 0, value=True, n_policy=n_policy), n_policy
+
+    def finish(self, handle):
+        t, npol = handle
+        out = self.engine.wait(t)
+        probs = normalise_like_categorical(out["probs"]) if npol else np.zeros((0, 81), np.float32)
+        return probs, out["value"]
+
+    def __call__(self, feats, n_policy):
+        return self.finish(self.submit(feats, n_policy))
+
+
+class CallableEvaluator:
+    """Any pair of callables policy(x)->logits, value(x)->[B] (CPU tests use the oracle nets)."""
+
+    def __init__(self, policy_fn, value_fn):
+        self.policy_fn, self.value_fn = policy_fn, value_fn
+        self.positions = self.batches = 0
+
+    def submit(self, feats, n_policy):
+        return feats.copy(), n_policy
+
+    def finish(self, handle):
+        import torch
+        feats, npol = handle
+        self.positions += len(feats)
+        self.batches += 1
+        x = feats.astype(np.float32)
+        if npol:
+            lg = torch.from_numpy(np.asarray(self.policy_fn(x[:npol]), dtype=np.float32))
+            probs = normalise_like_categorical(torch.softmax(lg, dim=1).numpy())
+        else:
+            probs = np.zeros((0, 81), np.float32)
+        return probs, np.asarray(self.value_fn(x), dtype=np.float32).reshape(-1)
+
+    def __call__(self, feats, n_policy):
+        return self.finish(self.submit(feats, n_policy))
+
+
+def run_pools(pools, evaluator, progress=None):
+    """Drive one or two pools to completion.  With two pools the host advances one while the
+    evaluator (GPU) works on the other's batch."""
+    inflight = [None] * len(pools)
+    live = [True] * len(pools)
+    steps = 0
+    while any(live) or any(h is not None for h in inflight):
+        for i, pool in enumerate(pools):
+            if inflight[i] is not None:
+                probs, values = evaluator.finish(inflight[i])
+                pool.deliver(probs, values)
+                inflight[i] = None
+            if live[i]:
+                feats, npol = pool.collect()
+                if len(feats) == 0:
+                    live[i] = False
+                else:
+                    inflight[i] = evaluator.submit(feats, npol)
+                    steps += 1
+        if progress is not None:
+            progress(steps, pools)
+    return steps
+
+
+STATS_FIELDS = ["games", "black_wins", "white_wins", "plies", "sum_score", "value_evals", "policy_evals", "requests"]
+STATS_LEN = len(STATS_FIELDS) + 81  # + histogram of first moves
+
+
+def pool_stats(pools):
+    s = np.zeros(STATS_LEN, np.float64)
+    for p in pools:
+        for g in range(p.n):
+            gi = p.info(g)
+            mv = p.moves(g)
+            s[0] += 1
+            s[1] += gi["score"] > 0
+            s[2] += gi["score"] <= 0
+            s[3] += gi["n_moves"]
+            s[4] += gi["score"]
+            s[5] += gi["n_value_evals"]
+            s[6] += gi["n_policy_evals"]
+            s[7] += gi["n_requests"]
+            if mv and mv[0] >= 0:
+                s[len(STATS_FIELDS) + mv[0]] += 1
+    return s
+
+
+def all_reduce_stats(stats, device=None):
+    """The generation's single collective: sum the statistics vector over ranks (world 1: no-op)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return stats, 0.0
+    t = torch.from_numpy(stats.copy())
+    if device is not None:
+        t = t.to(device)
+    t0 = time.perf_counter()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    return t.cpu().numpy(), time.perf_counter() - t0
+
+
+def shard_game_ids(n_games, rank, world):
+    return [g for g in range(n_games) if g % world == rank]
+
+
+def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
+              sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=2,
+              reduce_device=None, progress=None, prune=1, record_visits=0):
+    """Play this rank's share of a generation; returns (local result dict, reduced stats dict)."""
+    gids = shard_game_ids(n_games, rank, world)
+    prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
+                        sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits)
+    n_pools = max(1, min(n_pools, len(gids))) if gids else 0
+    parts = [gids[i::n_pools] for i in range(n_pools)]
+    pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
+    t0 = time.perf_counter()
+    steps = run_pools(pools, evaluator, progress)
+    dt = time.perf_counter() - t0
+    games = {}
+    for part, pool in zip(parts, pools):
+        for i, g in enumerate(part):
+            games[g] = {"moves": pool.moves(i), "score": pool.info(i)["score"]}
+    local = pool_stats(pools) if pools else np.zeros(STATS_LEN)
+    total, t_reduce = all_reduce_stats(local, reduce_device)
+    for p in pools:
+        p.close()
+    named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}
+    named["first_move_hist"] = total[len(STATS_FIELDS):].astype(int).tolist()
+    return ({"games": games, "seconds": dt, "steps": steps, "local_stats": local, "allreduce_s": t_reduce}, named)
+
+
+def main():
+    ap = argparse.ArgumentParser(description="MCTS self-play generation on the HIP engine")
+    ap.add_argument("--games", type=int, default=512)
+    ap.add_argument("--rollouts", type=int, default=400)
+    ap.add_argument("--max-turns", type=int, default=80)
+    ap.add_argument("--policy", default=None, help=".pt or .bkw policy weights (default: tests/golden/policy_19.bkw)")
+    ap.add_argument("--value", default=None)
+    ap.add_argument("--max-batch", type=int, default=8192)
+    ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--out", default=None, help="write this rank's games as JSON")
+    args = ap.parse_args()
+
+    import torch
+    from .bkw import load_bkw
+    from .engine import LeafEngine
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def load(path, default):
+        path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", default)
+        if path.endswith(".bkw"):
+            return load_bkw(path)
+        ck = torch.load(path, map_location="cpu")
+        return ck.get("model_state_dict", ck)
+
+    eng = LeafEngine(load(args.policy, "policy_19.bkw"), load(args.value, "value_synth.bkw"), device_id=local_rank,
+                     max_batch=args.max_batch)
+    ev = EngineEvaluator(eng)
+    local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
+                             max_turns=args.max_turns, cap=args.max_batch, threads=args.threads,
+                             reduce_device=torch.device("cuda", local_rank))
+    secs = local["seconds"]
+    if world > 1:
+        t = torch.tensor([secs], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+    if rank == 0:
+        print(json.dumps({"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
+                          "n_gpus": world, "rollouts_per_move": args.rollouts, "plies": total["plies"],
+                          "leaf_evals": total["value_evals"], "leaf_evals_per_s_per_gpu": total["value_evals"] / secs / world,
+                          "black_wins": total["black_wins"], "white_wins": total["white_wins"],
+                          "allreduce_ms": local["allreduce_s"] * 1e3, "mean_batch": ev.positions / max(1, ev.batches)}))
+    if args.out:
+        with open(f"{args.out}.rank{rank}.json", "w") as f:
+            json.dump({str(k): v for k, v in local["games"].items()}, f)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+/*
+ * bokego_tree.h -- C ABI of the native PUCT search core / lock-step game pool (libbkgo.so, host only).
+ *
+ * Replaces, for many concurrent games, the reference's per-tree Python loop
+ *   MCTS.rollout / _descend / _puct_select / _expand / _backpropagate / choose / set_root
+ *   (bokego/mcts.py:110-234) and the lazy node accessors Go_MCTS.dist / .value (mcts.py:371-403),
+ * whose cache misses are exactly "enqueue a leaf".  The pool turns those misses into batches:
+ *
+ *   for (;;) {
+ *       B = bk_pool_collect(pool, feats, cap, &n_policy);   // every game runs until it needs a network
+ *       if (B == 0) break;                                   // all games finished
+ *       bk_submit_prefix(engine, feats, BK_FEATS_U8, B, n_policy, PROBS|VALUE, NULL, probs, values);
+ *       ... renormalise probs rows as torch's Categorical does (nnet.py:274) ...
+ *       bk_pool_deliver(pool, probs, values);
+ *   }
+ */
+#ifndef BOKEGO_TREE_H
+#define BOKEGO_TREE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bk_search_params {
+    int32_t rollouts;      /* per move (BASELINE config 3: 1600, config 4: 400)                 */
+    int32_t expand_thresh; /* MCTS kwarg expand_thresh, default 100 (mcts.py:61)                */
+    double c_puct;         /* exploration_weight, default 4.0 (mcts.py:63)                      */
+    float noise_weight;    /* Dirichlet(0.1) mix at every new root, default 0 (mcts.py:64)      */
+    int32_t sample_plies;  /* self-play: first plies sampled ~ visit counts (0 = always argmax) */
+    int32_t max_turns;     /* MAX_TURNS = 80 (mcts.py:13)                                       */
+    int32_t eager;         /* 1: value of every new child is requested at expansion             */
+    float komi;            /* 5.5 (go.py:45)                                                    */
+    int32_t record_visits; /* 1: keep every ply's root-child visit counts (self-play records)    */
+    int32_t prune;         /* 0: keep every node ever created, like the reference's never-pruned
+                              Q/N/V dicts (a position from an abandoned branch that is reached again
+                              keeps its statistics); 1: drop everything outside the new root's
+                              subtree at each move (bounded memory for long self-play runs)      */
+} bk_search_params;
+
+typedef struct bk_game_info {
+    int32_t done;
+    int32_t n_moves;
+    float score;           /* Tromp-Taylor area score of the final position, black - white - komi */
+    int32_t n_nodes;
+    uint64_t n_value_evals, n_policy_evals, n_requests;
+    int32_t root_N;
+    int32_t reserved;
+    double root_V;
+} bk_game_info;
+
+typedef struct bk_pool bk_pool;
+
+void bk_search_params_default(bk_search_params *p);
+/* seeds[i] drives game i's noise / move sampling: results do not depend on how games are grouped */
+bk_pool *bk_pool_create(int n_games, const bk_search_params *prm, const uint64_t *seeds, int threads);
+void bk_pool_destroy(bk_pool *p);
+
+/* Advance every unfinished game until it needs network outputs; write the requested positions'
+ * feature planes (uint8 [B][27][9][9]) to feats: first the n_policy positions that need policy
+ * (+value), then the value-only ones.  Returns B (0 when every game is over).  cap >= 82. */
+int bk_pool_collect(bk_pool *p, uint8_t *feats, int cap, int *n_policy);
+/* probs: [n_policy][81] (already Categorical-normalised), values: [B], same order as collected */
+void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
+
+int bk_pool_n_games(const bk_pool *p);
+int bk_pool_n_done(const bk_pool *p);
+int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);
+int bk_pool_game_moves(const bk_pool *p, int g, int16_t *out, int cap);
+/* visit counts of the root's children when ply `ply` was chosen (needs record_visits); returns their number */
+int bk_pool_game_visits(const bk_pool *p, int g, int ply, int16_t *moves, int32_t *N);
+/* root children of game g in ascending move order; returns their number */
+int bk_pool_root_children(const bk_pool *p, int g, int16_t *moves, int32_t *N, double *V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

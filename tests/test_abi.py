@@ -10,8 +10,8 @@ import pytest
 from conftest import GOLDEN, REPO
 
 
-def _header_functions():
-    src = open(os.path.join(REPO, "include", "bokego_amd.h")).read()
+def _header_functions(name="bokego_amd.h"):
+    src = open(os.path.join(REPO, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(bk_[a-z0-9_]+)\s*\(", src)))
 
@@ -96,3 +96,18 @@ def test_bkw_roundtrip(tmp_path):
     assert "conv.1.num_batches_tracked" in tsd and tsd["conv.3.weight"].dtype == torch.float32
     again = state_dict_to_tensors(tsd)
     assert all(np.array_equal(again[k], sd[k]) for k in sd)
+
+
+def test_host_library_exports_go_and_tree_headers():
+    """libbkgo.so (board, features, tree pool) exports everything bokego_go.h / bokego_tree.h declare."""
+    import ctypes as C
+    from bokego_amd import go, selfplay
+    lib = go.golib()
+    selfplay.treelib()
+    for hdr, table in (("bokego_go.h", go.GO_SYMBOLS), ("bokego_tree.h", selfplay.TREE_SYMBOLS)):
+        fns = _header_functions(hdr)
+        assert fns and set(fns) == set(table), (hdr, set(fns) ^ set(table))
+        for f in fns:
+            assert hasattr(lib, f)
+    assert lib.bk_go_abi_version() == 1
+    assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 48 and C.sizeof(selfplay.GameInfo) == 56

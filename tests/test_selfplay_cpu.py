@@ -1,0 +1,157 @@
+"""Host logic of config 4 on CPU: the native tree pool equals the Python MCTS visit for visit, games do
+not depend on sharding, and the end-of-generation all-reduce works with world_size 2 (gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from bokego_amd import go, selfplay
+from bokego_amd.bkw import load_bkw
+from bokego_amd.mcts import MCTS, Go_MCTS
+
+from conftest import GOLDEN, REPO
+
+
+class FakeNets:
+    """cheap deterministic stand-in networks (a fixed random linear map of the planes)"""
+
+    def __init__(self):
+        rng = np.random.default_rng(5)
+        self.Wp = (rng.standard_normal((2187, 81)) * 0.05).astype(np.float32)
+        self.wv = (rng.standard_normal(2187) * 0.02).astype(np.float32)
+
+    def policy(self, x):
+        return np.asarray(x, np.float32).reshape(len(x), -1) @ self.Wp
+
+    def value(self, x):
+        return np.tanh(np.asarray(x, np.float32).reshape(len(x), -1) @ self.wv)
+
+
+class _Wrap:
+    def __init__(self, fn, value=False):
+        self.fn, self.value = fn, value
+
+    def to(self, d):
+        return self
+
+    def __call__(self, x):
+        o = np.asarray(self.fn(x.numpy()), np.float32)
+        return torch.from_numpy(o.reshape(-1, 1) if self.value else o)
+
+
+def _play_python(policy_fn, value_fn, rollouts, n_moves, **kw):
+    import bokego_amd.mcts as M
+    old, M.MAX_TURNS = M.MAX_TURNS, n_moves - 1      # same game length as the native pool below
+    try:
+        tree = MCTS(Go_MCTS(), _Wrap(policy_fn), _Wrap(value_fn, True), **kw)
+        moves, visits = [], []
+        for _ in range(n_moves):
+            tree.rollout(rollouts)
+            visits.append({c.mv: tree.N[c] for c in tree.children[tree.root]})
+            moves.append(tree.choose().last_move)
+        return moves, visits, {c.mv: (tree.N[c], tree.V[c]) for c in tree.children.get(tree.root, [])}
+    finally:
+        M.MAX_TURNS = old
+
+
+def _play_native(policy_fn, value_fn, rollouts, n_moves, **kw):
+    prm = selfplay.search_params(rollouts=rollouts, max_turns=n_moves - 1, record_visits=1, **kw)
+    pool = selfplay.GamePool([1], prm, cap=256, threads=1)
+    selfplay.run_pools([pool], selfplay.CallableEvaluator(policy_fn, value_fn))
+    assert pool.info(0)["done"] == 1
+    return pool.moves(0), [pool.visits(0, i) for i in range(n_moves)], pool.root_children(0)
+
+
+def test_native_pool_equals_python_mcts_with_oracle_nets():
+    from oracle.oracle import OraclePolicy, OracleValue
+    P = OraclePolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")))
+    V = OracleValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw")))
+    pm, pv, _ = _play_python(P, V, 120, 4, expand_thresh=12)
+    nm, nv, _ = _play_native(P, V, 120, 4, expand_thresh=12)
+    assert nm == pm and nv == pv
+
+
+def test_native_pool_equals_python_mcts_deep():
+    f = FakeNets()
+    pm, pv, pend = _play_python(f.policy, f.value, 400, 12, expand_thresh=6)
+    nm, nv, nend = _play_native(f.policy, f.value, 400, 12, expand_thresh=6)
+    assert nm == pm and nv == pv
+    assert nend == pend                                  # final subtree: visits and summed values bit-identical
+
+
+def _run_world(world, **kw):
+    f = FakeNets()
+    games, stats = {}, np.zeros(selfplay.STATS_LEN)
+    for rank in range(world):
+        ev = selfplay.CallableEvaluator(f.policy, f.value)
+        local, _ = selfplay.self_play(ev, rank=rank, world=world, **kw)
+        assert set(local["games"]) == set(selfplay.shard_game_ids(kw["n_games"], rank, world))
+        games.update(local["games"])
+        stats += local["local_stats"]
+    return games, stats
+
+
+KW = dict(n_games=7, rollouts=40, expand_thresh=4, max_turns=9, noise_weight=0.25, sample_plies=4, cap=700, threads=2)
+
+
+def test_games_do_not_depend_on_world_size_or_pool_split():
+    g1, s1 = _run_world(1, **KW)
+    g2, s2 = _run_world(2, **KW)
+    g4, s4 = _run_world(4, n_pools=1, **KW)
+    assert g1 == g2 == g4 and np.array_equal(s1, s2) and np.array_equal(s1, s4)
+    assert len({tuple(g["moves"]) for g in g1.values()}) > 1      # seeds really differ per game
+    assert all(len(g["moves"]) == 10 for g in g1.values())        # turn > max_turns ends the game
+    assert s1[0] == 7 and s1[1] + s1[2] == 7 and s1[3] == 70
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = FakeNets()
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    local, total = selfplay.self_play(ev, rank=rank, world=world, **KW)
+    q.put((rank, total, {k: v["moves"] for k, v in local["games"].items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_end_of_generation_allreduce_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g1, s1 = _run_world(1, **KW)
+    totals = [r[1] for r in res]
+    assert totals[0] == totals[1]                                   # every rank holds the reduced vector
+    assert totals[0]["games"] == 7 and totals[0]["plies"] == s1[3] and totals[0]["value_evals"] == s1[5]
+    assert totals[0]["first_move_hist"] == s1[len(selfplay.STATS_FIELDS):].astype(int).tolist()
+    merged = {}
+    for r in res:
+        merged.update(r[2])
+    assert merged == {k: v["moves"] for k, v in g1.items()}
+
+
+def test_pool_respects_cap_and_counts():
+    f = FakeNets()
+    prm = selfplay.search_params(rollouts=30, expand_thresh=3, max_turns=5)
+    pool = selfplay.GamePool(list(range(10)), prm, cap=200, threads=2)   # ~2 games' requests fit per step
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    steps = selfplay.run_pools([pool], ev)
+    assert pool.n_done == 10 and steps > 10
+    assert all(len(pool.moves(g)) == 6 for g in range(10))
+    # identical seeds-independent search (no noise, no sampling) -> identical games
+    assert len({tuple(pool.moves(g)) for g in range(10)}) == 1
+    nv = sum(pool.info(g)["n_value_evals"] for g in range(10))
+    npol = sum(pool.info(g)["n_policy_evals"] for g in range(10))
+    # every evaluated position is a new value, except policy requests for nodes whose value was known
+    assert nv <= ev.positions <= nv + npol
