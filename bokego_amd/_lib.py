@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbokego_amd.so")
+LIB_PATH = os.environ.get("BK_LIB_PATH") or os.path.join(_HERE, "libbokego_amd.so")  # BK_LIB_PATH: diagnostic builds
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 

@@ -20,6 +20,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
+#define BK_STAMP_BLOCKS 16384
 constexpr double kBnEps = 1e-5;  // torch.nn.BatchNorm default, nnet.py:33,98-99
 
 struct Slot {  // one in-flight host-buffer request
@@ -52,6 +53,7 @@ struct bk_engine {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
     size_t ev_head = 0, ev_pending = 0;
+    unsigned long long* d_stamps = nullptr;  // diagnostic builds only
 };
 
 namespace {
@@ -74,10 +76,10 @@ bool trunk_ok(const bk_trunk_weights& t) {
     return t.head_w && t.head_b;
 }
 
-// Fold BatchNorm2d (eval) into conv l and emit the per-wave MFMA fragment order consumed by
-// conv_layer<> in bk_kernels.hip:
-//   index = ((w*TAPS + t)*G + g)*256 + lane*4 + j
-//   cout = 32w + (lane&31), cin = 8g + 4(lane>>5) + j, tap t = ky*K + kx
+// Fold BatchNorm2d (eval) into conv l and emit the MFMA fragment order consumed by conv_layer<>
+// in bk_kernels.hip:
+//   index = (((tap*G + g)*4 + ntile)*64 + lane)*4 + j
+//   cout = 32*ntile + (lane&31), cin = 8g + 4(lane>>5) + j, tap = ky*K + kx
 void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
     wfrag.assign(BK_WFRAG_FLOATS + BK_WFRAG_PAD_FLOATS, 0.f);
     bias.assign(7 * 128, 0.f);
@@ -89,17 +91,17 @@ void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vecto
             scale[co] = (double)t.bn_w[l][co] / std::sqrt((double)t.bn_var[l][co] + kBnEps);
             bias[l * 128 + co] = (float)(((double)t.conv_b[l][co] - (double)t.bn_mean[l][co]) * scale[co] + (double)t.bn_b[l][co]);
         }
-        for (int w = 0; w < 4; ++w)
-            for (int tp = 0; tp < TAPS; ++tp)
-                for (int g = 0; g < G; ++g)
+        for (int tp = 0; tp < TAPS; ++tp)
+            for (int g = 0; g < G; ++g)
+                for (int nt = 0; nt < 4; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 4; ++j) {
-                            const int co = 32 * w + (lane & 31), ci = 8 * g + 4 * (lane >> 5) + j;
+                            const int co = 32 * nt + (lane & 31), ci = 8 * g + 4 * (lane >> 5) + j;
                             float v = 0.f;
                             if (ci < cin) v = (float)((double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co]);
-                            wfrag[base + (((size_t)w * TAPS + tp) * G + g) * 256 + lane * 4 + j] = v;
+                            wfrag[base + ((((size_t)tp * G + g) * 4 + nt) * 64 + lane) * 4 + j] = v;
                         }
-        base += (size_t)4 * TAPS * G * 256;
+        base += (size_t)TAPS * G * 1024;
     }
 }
 
@@ -201,6 +203,9 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     a.probs = (want & BK_WANT_PROBS) ? d_probs : nullptr;
     a.values = (want & BK_WANT_VALUE) ? d_values : nullptr;
     if (a.B_policy + a.B_value == 0) return BK_OK;
+#ifdef BK_STAMPS
+    a.stamps = e->d_stamps;
+#endif
     const int nb = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
     bool timed = false;
     size_t slot = 0;
@@ -306,6 +311,10 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
         if ((rc = upload(e, w2, &e->net[1].lin2_w))) return bail(rc);
         e->net[1].lin2_b = h.lin2_b[0];
     }
+#ifdef BK_STAMPS
+    TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
+    e->dev_allocs.push_back(e->d_stamps);
+#endif
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);
     e->ev_ring.resize(512);
@@ -449,6 +458,16 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
 }
 
 int bk_engine_max_batch(bk_engine* e) { return e ? e->max_batch : BK_ERR_ARG; }
+
+#ifdef BK_STAMPS
+// diagnostic builds only (not part of include/bokego_amd.h)
+int bk_debug_read_stamps(bk_engine* e, unsigned long long* out, int n_blocks) {
+    if (!e || n_blocks > BK_STAMP_BLOCKS) return BK_ERR_ARG;
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(out, e->d_stamps, (size_t)n_blocks * 4 * 32 * 8, hipMemcpyDeviceToHost));
+    return BK_OK;
+}
+#endif
 
 const char* bk_last_error(bk_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 

@@ -4,13 +4,12 @@
 #include <stdint.h>
 
 // fragment-ordered weight buffer geometry (floats)
-// layer 0: 4 waves x 25 taps x 4 groups x (64 lanes x 4)   layers 1..6: 4 x 9 x 16 x 256
-#define BK_L0_WAVE_FLOATS (25 * 4 * 256)
-#define BK_L0_FLOATS (4 * BK_L0_WAVE_FLOATS)
-#define BK_L3_WAVE_FLOATS (9 * 16 * 256)
-#define BK_L3_FLOATS (4 * BK_L3_WAVE_FLOATS)
+// per layer: [tap][group of 8 cin][cout tile (4 x 32)][lane (64)][4]
+// layer 0: 25 taps x 4 groups x 1024   layers 1..6: 9 x 16 x 1024
+#define BK_L0_FLOATS (25 * 4 * 1024)
+#define BK_L3_FLOATS (9 * 16 * 1024)
 #define BK_WFRAG_FLOATS (BK_L0_FLOATS + 6 * BK_L3_FLOATS)
-#define BK_WFRAG_PAD_FLOATS 1024  // the B prefetch reads one 4 KiB block past the last slice
+#define BK_WFRAG_PAD_FLOATS 4096  // the B prefetch reads one block (4 groups, 16 KiB) past the last layer
 
 #define BK_FEATS_F32_ 0
 #define BK_FEATS_U8_ 1
@@ -36,6 +35,7 @@ struct bk_eval_args {
     float* logits;         // [B][81] or null
     float* probs;          // [B][81] or null
     float* values;         // [B] or null
+    unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
 int bk_pick_nb(int B_policy, int B_value, int n_cu);

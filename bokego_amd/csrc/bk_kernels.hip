@@ -30,12 +30,29 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef BK_EXP
+#define BK_EXP 0
+#endif
+#ifdef BK_STAMPS
+// Diagnostic build only: lane 0 of every wave records the shader clock at phase boundaries into a
+// buffer nothing else reads (cdna_hip_programming.md "In-kernel stamps").  Never in the shipped .so.
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long _t;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+        if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (k)] = _t;      \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 // ---- LDS layouts -------------------------------------------------------------------------
 // 128-channel activations: position p = (10*b + 1 + y)*10 + (x + 1); 512 B per position.
 __device__ __forceinline__ int pos3(int b, int y, int x) { return (10 * b + 1 + y) * 10 + x + 1; }
-__device__ __forceinline__ int act_addr(int p, int c) { return p * 128 + ((((c >> 2) ^ (p & 15)) << 2) | (c & 3)); }
 // layer-0 input (27 channels padded to 32): 11-column rows with two shared halo columns,
 // two zero rows between boards (5x5 taps); 128 B per position.
 __device__ __forceinline__ int pos5(int b, int y, int x) { return (11 * b + 2 + y) * 11 + x + 2; }
@@ -43,95 +60,178 @@ __device__ __forceinline__ int in_addr(int p, int c) { return p * 32 + ((((c >> 
 
 template <int NB>
 struct Geo {
-    static constexpr int MT = (81 * NB + 31) / 32;  // 32-row MFMA tiles
+    static constexpr int MT = (81 * NB + 31) / 32;  // 32-row MFMA tiles in the workgroup
     static constexpr int NPOS = 100 * NB + 11;      // positions in the 128-ch layout
     static constexpr int NP0 = 121 * NB + 24;       // positions in the layer-0 layout
-    static constexpr int ROWPOS_FLOATS = MT * 16;   // MT*32 int16
+    // the 4 waves form a WM x WN grid over [rows x couts]; a wave owns MTW row tiles x NT cout tiles.
+    // 2x2 halves the LDS reads per MFMA (an A fragment feeds NT MFMAs): on the fp32 MFMA every
+    // non-MFMA instruction costs issue time, so instructions per MFMA is what is minimised.
+    static constexpr int WM = (MT % 2 == 0) ? 2 : 1;
+    static constexpr int WN = 4 / WM;
+    static constexpr int NT = 4 / WN;
+    static constexpr int MTW = MT / WM;
+    static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one slot per thread)
     static constexpr int HS_FLOATS = NB * 96;
-    static constexpr int LDS_BYTES = (NPOS * 128 + ROWPOS_FLOATS + HS_FLOATS) * 4;
+    static constexpr int LDS_BYTES = (NPOS * 128 + DUMMY_FLOATS + HS_FLOATS) * 4;
 };
 
-// One conv layer: acc[mt] (32 rows x 32 couts of this wave) = sum over taps, cin.
-// wl: this wave's slice of the layer's fragment-ordered weights.
+// One conv layer for one wave: acc[mt][nt] (32 rows x 32 couts each) = sum over taps, cin.
+// wl: the layer's fragment-ordered weights [tap][group of 8 cin][cout tile (4)][lane][4].
 template <int NB, bool FIRST>
 __device__ __forceinline__ void conv_layer(const float* act, const float* __restrict__ wl,
-                                           f32x16 (&acc)[Geo<NB>::MT], int lane) {
-    constexpr int MT = Geo<NB>::MT;
+                                           f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
+    constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
     constexpr int KW = FIRST ? 5 : 3;
     constexpr int TAPS = KW * KW;
     constexpr int NBLK = FIRST ? 1 : 4;  // blocks of 4 channel-groups (8 cin each) per tap
     const int h = lane >> 5, l32 = lane & 31;
 
-    int pbase[MT];
+    int pbase[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int r = mt * 32 + l32;
+    for (int mt = 0; mt < MTW; ++mt) {
+        int r = (wm * MTW + mt) * 32 + l32;
         if (r >= 81 * NB) r = 0;  // padding rows compute garbage from a valid address; never stored
         const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
         pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wl) + lane;
-    f32x4 Bc[4], Bn[4];
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) Bc[gg] = wp[gg * 64];
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-#pragma unroll 1
-    for (int t = 0; t < TAPS; ++t) {
+    // B fragments: block b (4 groups of 8 cin) of the layer is 16 KiB [group][cout tile][lane][4];
+    // this wave reads cout tiles wn*NT .. wn*NT+NT-1: NT coalesced 1 KiB loads per group, addressed
+    // as (wave-uniform base) + (lane offset) so the per-block pointer bump is scalar work.
+    const float* wv = wl + (wn * NT) * 256;
+    const int lane4 = lane * 4;
+    auto load_b = [&](f32x4 (&B)[4][NT], int blk) {
+        const float* wb = wv + (size_t)blk * 4096;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                B[gg][nt] = *reinterpret_cast<const f32x4*>(wb + (gg * 4 + nt) * 256 + lane4);
+    };
+
+    // A fragments: byte address = abase + ((chunk<<4) ^ (swizzle<<4)): one v_xad_u32 per read.
+    const char* actb = reinterpret_cast<const char*>(act);
+    int ab[MTW], swb[MTW];
+    auto tap_setup = [&](int t) {
         const int ky = t / KW, kx = t - ky * KW;
         const int off = FIRST ? (ky - 2) * 11 + (kx - 2) : (ky - 1) * 10 + (kx - 1);
-        int abase[MT], sw[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
             const int pa = pbase[mt] + off;
-            abase[mt] = FIRST ? pa * 32 : pa * 128;
-            sw[mt] = FIRST ? ((pa >> 1) & 7) : (pa & 15);
+            ab[mt] = FIRST ? pa * 128 : pa * 512;
+            swb[mt] = (FIRST ? ((pa >> 1) & 7) : (pa & 15)) << 4;
         }
-#pragma unroll 1
-        for (int gb = 0; gb < NBLK; ++gb) {
-            const int blk = t * NBLK + gb;
-            // prefetch the next block's B fragments (one block = 4 KiB per wave) from L2
+    };
+    const int hb = h << 4;
+    auto read_a = [&](f32x4 (&A)[MTW], int chunkb) {
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) Bn[gg] = wp[((blk + 1) * 4 + gg) * 64];
+        for (int mt = 0; mt < MTW; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(actb + (ab[mt] + (chunkb ^ swb[mt])));
+    };
+
+    // Software pipeline, all through register ping-pong (no copies: on this chip the fp32 MFMA
+    // shares the vector ALU, so every extra VALU instruction in the loop is lost MFMA time):
+    //   group g+1's A fragments are read from LDS during group g's MFMAs,
+    //   block b+1's B fragments are fetched from L2 during block b's 128 MFMAs.
+    f32x4 A0[MTW], A1[MTW], B0[4][NT], B1[4][NT];
+    constexpr int NBLOCKS = TAPS * NBLK;
+
+    // one block = 4 groups; `blk` is the block's index in the layer, Bc its fragments, Bn receives
+    // the next block's.  Group parity alternates A0/A1; a block has an even number of groups.
+    auto do_block = [&](int blk, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT]) {
+        load_b(Bn, blk + 1);  // the last block over-reads into the next layer / the pad: harmless
+        __builtin_amdgcn_sched_barrier(0);
+        const int gb = NBLK == 1 ? 0 : (blk & (NBLK - 1));
+        const bool tap_end = gb == NBLK - 1;
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                const int chunk = (gb * 4 + gg) * 2 + h;
-                f32x4 A[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    A[mt] = *reinterpret_cast<const f32x4*>(act + abase[mt] + ((chunk ^ sw[mt]) << 2));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt][j], Bc[gg][j], acc[mt], 0, 0, 0);
+        for (int gg = 0; gg < 4; ++gg) {
+            f32x4 (&Ac)[MTW] = (gg & 1) ? A1 : A0;
+            f32x4 (&An)[MTW] = (gg & 1) ? A0 : A1;
+            int chunkb;
+            if (gg == 3) {
+                if (tap_end) {  // next group is group 0 of the next tap
+                    const int t = blk / NBLK;
+                    tap_setup(t + 1 < TAPS ? t + 1 : t);
+                    chunkb = hb;
+                } else {
+                    chunkb = ((gb * 4 + 4) << 5) | hb;
+                }
+            } else {
+                chunkb = ((gb * 4 + gg + 1) << 5) | hb;
             }
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) Bc[gg] = Bn[gg];
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][0], Bc[gg][nt][0], acc[mt][nt], 0, 0, 0);
+            read_a(An, chunkb);
+            __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued right after the first MFMA round
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][j], Bc[gg][nt][j], acc[mt][nt], 0, 0, 0);
         }
+    };
+
+    load_b(B0, 0);
+    tap_setup(0);
+    read_a(A0, hb);
+#pragma unroll 1
+    for (int blk = 0; blk + 1 < NBLOCKS; blk += 2) {
+        do_block(blk, B0, B1);
+        do_block(blk + 1, B1, B0);
+    }
+    if (NBLOCKS & 1) do_block(NBLOCKS - 1, B0, B1);
+}
+
+// position of flat row r (board r/81, point r%81) in the 128-channel layout; constexpr so the
+// epilogue's addresses are immediates
+constexpr int row_pos3(int r) { return (10 * (r / 81) + 1 + (r % 81) / 9) * 10 + (r % 81) % 9 + 1; }
+
+// bias + ReLU + in-place store of this wave's tiles.  Accumulator register i of row tile T holds
+// row T*32 + (i&3) + 8*(i>>2) + 4*h (h = lane>>5): with the wave's row block WMI a template
+// constant both candidates are compile-time constants, so an address is two selects on h plus the
+// channel swizzle -- no table, no branches.  Rows beyond 81*NB (padding of the last tile) are
+// steered into a per-thread dummy slot.
+template <int NB, int WMI>
+__device__ __forceinline__ void store_tiles(float* act, int dummy_addr, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
+                                            const float* __restrict__ bias, int col0, int h) {
+    constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = col0 + 32 * nt;
+        const float bv = bias[col];
+        const int cchunk = col >> 2, clow = col & 3;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r0 = (WMI * MTW + mt) * 32 + (i & 3) + 8 * (i >> 2), r1 = r0 + 4;
+                const bool ok0 = r0 < 81 * NB, ok1 = r1 < 81 * NB;
+                const int p0 = ok0 ? row_pos3(r0) : 0, p1 = ok1 ? row_pos3(r1) : 0;
+                const int base = h ? p1 * 128 : p0 * 128;
+                const int swz = h ? (p1 & 15) : (p0 & 15);
+                int addr = base + (((cchunk ^ swz) << 2) | clow);
+                if (!(ok0 && ok1)) addr = (h ? ok1 : ok0) ? addr : dummy_addr;
+                const float v = acc[mt][nt][i] + bv;
+                act[addr] = v > 0.f ? v : 0.f;
+            }
     }
 }
 
-// bias + ReLU + in-place store of this wave's 32 couts
 template <int NB>
-__device__ __forceinline__ void store_layer(float* act, const short* rowpos, const f32x16 (&acc)[Geo<NB>::MT],
-                                            float bias, int col, int h) {
-    constexpr int MT = Geo<NB>::MT;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int p = rowpos[r];
-            if (p >= 0) {
-                float v = acc[mt][i] + bias;
-                act[act_addr(p, col)] = v > 0.f ? v : 0.f;
-            }
-        }
+__device__ __forceinline__ void store_layer(float* act, int dummy_addr, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
+                                            const float* __restrict__ bias, int wm, int col0, int h) {
+    if (Geo<NB>::WM == 1 || wm == 0) store_tiles<NB, 0>(act, dummy_addr, acc, bias, col0, h);
+    else store_tiles<NB, 1>(act, dummy_addr, acc, bias, col0, h);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -151,8 +251,8 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     constexpr int MT = G::MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem;
-    short* rowpos = reinterpret_cast<short*>(smem + G::NPOS * 128);
-    float* hs = smem + G::NPOS * 128 + G::ROWPOS_FLOATS;
+    const int dummy_addr = G::NPOS * 128 + threadIdx.x;
+    float* hs = smem + G::NPOS * 128 + G::DUMMY_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,12 +278,9 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     const int b0 = task * NB;
     const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
+    STAMP(0);
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
     for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r = tid; r < MT * 32; r += 256) {
-        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
-        rowpos[r] = r < 81 * NB ? (short)pos3(b, y, x) : (short)-1;
-    }
     __syncthreads();
     if (a.feats_dtype == BK_FEATS_F32_) {
         const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
@@ -200,25 +297,39 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     }
     __syncthreads();
 
-    f32x16 acc[MT];
-    const int col = 32 * wave + (lane & 31);
+    STAMP(1);
+    f32x16 acc[G::MTW][G::NT];
+    const int wm = wave / G::WN, wn = wave - wm * G::WN;
+    const int col0 = wn * (32 * G::NT) + (lane & 31);
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer<NB, true>(act, P.wfrag + wave * (BK_L0_WAVE_FLOATS), acc, lane);
+    conv_layer<NB, true>(act, P.wfrag, acc, lane, wm, wn);
+    STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: clear it all (halo must be zero)
     for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    store_layer<NB>(act, rowpos, acc, P.bias[col], col, h);
+    STAMP(3);
+    store_layer<NB>(act, dummy_addr, acc, P.bias, wm, col0, h);
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
 
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        conv_layer<NB, false>(act, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS + wave * BK_L3_WAVE_FLOATS, acc, lane);
+        conv_layer<NB, false>(act, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn);
+        STAMP(2 + 4 * L);
         __syncthreads();
-        store_layer<NB>(act, rowpos, acc, P.bias[L * 128 + col], col, h);
+        STAMP(3 + 4 * L);
+        // make the lane's column / half opaque per layer: otherwise the 256 store addresses are
+        // hoisted out of this loop as loop invariants and live (spilled) across the MFMA loops
+        int c0 = col0, hh = h;
+        asm volatile("" : "+v"(c0), "+v"(hh));
+        store_layer<NB>(act, dummy_addr, acc, P.bias + L * 128, wm, c0, hh);
+        STAMP(4 + 4 * L);
         __syncthreads();
+        STAMP(5 + 4 * L);
     }
 
     // ---- heads: wave w handles board w ----
@@ -270,6 +381,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
             if (lane == 0 && a.values) a.values[bg] = tanhf(v);
         }
     }
+    STAMP(30);
 }
 
 template <int NB>
