@@ -5,8 +5,10 @@
 //   nnet.py:265-297 (policy_dist / value / policy_sample forward calls).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -31,6 +33,9 @@ struct Slot {  // one in-flight host-buffer request
     float *h_logits = nullptr, *h_probs = nullptr, *h_values = nullptr;
     void* d_in = nullptr;
     float *d_logits = nullptr, *d_probs = nullptr, *d_values = nullptr;
+    unsigned int* d_flag = nullptr;  // f16x2 overflow flag of this request
+    unsigned int* h_flag = nullptr;
+    int dtype = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
 };
@@ -42,6 +47,7 @@ struct bk_engine {
     int max_batch = 0;
     int n_cu = 256;
     bool has_policy = false, has_value = false;
+    int precision = BK_PRECISION_F16X2;
     hipStream_t stream = nullptr;
     std::vector<void*> dev_allocs;
     bk_net_params net[2]{};
@@ -53,6 +59,7 @@ struct bk_engine {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
     size_t ev_head = 0, ev_pending = 0;
+    unsigned int* d_dev_flag = nullptr;      // f16x2 overflow flag of the device-pointer path (sticky)
     unsigned long long* d_stamps = nullptr;  // diagnostic builds only
 };
 
@@ -105,6 +112,48 @@ void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vecto
     }
 }
 
+// f16x2 path: folded weights scaled by 2^e_l and split into fp16 hi/lo, in the fragment order of
+// conv_layer16<> (bk_kernels_f16.hip):
+//   index = (((ks*4 + ntile)*2 + piece)*64 + lane)*8 + j,  ks = tap*S + s
+//   cout = 32*ntile + (lane&31), cin = 16s + 8(lane>>5) + j
+constexpr float kSa16 = 16.f;  // activation scale (power of two): |activation| < 65504/16 representable
+void pack_trunk16(const bk_trunk_weights& t, std::vector<_Float16>& wfrag, std::vector<float>& bias16, float* cscale) {
+    wfrag.assign(BK16_WFRAG_HALFS + BK16_WFRAG_PAD_HALFS, (_Float16)0.f);
+    bias16.assign(7 * 128, 0.f);
+    size_t base = 0;
+    for (int l = 0; l < 7; ++l) {
+        const int K = l == 0 ? 5 : 3, cin = l == 0 ? 27 : 128, S = l == 0 ? 2 : 8, TAPS = K * K;
+        std::vector<double> scale(128);
+        double wmax = 0;
+        for (int co = 0; co < 128; ++co) {
+            scale[co] = (double)t.bn_w[l][co] / std::sqrt((double)t.bn_var[l][co] + kBnEps);
+            bias16[l * 128 + co] = (float)(kSa16 * (((double)t.conv_b[l][co] - (double)t.bn_mean[l][co]) * scale[co] + (double)t.bn_b[l][co]));
+            for (int i = 0; i < cin * TAPS; ++i) wmax = std::max(wmax, std::fabs((double)t.conv_w[l][(size_t)co * cin * TAPS + i] * scale[co]));
+        }
+        int el = wmax > 0 ? (int)std::floor(std::log2(32768.0 / wmax)) : 0;  // max |w| * 2^el <= 2^15
+        el = std::max(-14, std::min(el, 24));
+        const double sw = std::ldexp(1.0, el);
+        const double sa_in = l == 0 ? 1.0 : kSa16;
+        cscale[l] = (float)(kSa16 / (sa_in * sw));
+        for (int tp = 0; tp < TAPS; ++tp)
+            for (int sidx = 0; sidx < S; ++sidx)
+                for (int nt = 0; nt < 4; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * nt + (lane & 31), ci = 16 * sidx + 8 * (lane >> 5) + j;
+                            double w = 0;
+                            if (ci < cin) w = (double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co] * sw;
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (double)hi);
+                            const size_t ks = (size_t)tp * S + sidx;
+                            const size_t at = base + (((ks * 4 + nt) * 2) * 64 + lane) * 8 + j;
+                            wfrag[at] = hi;
+                            wfrag[at + 512] = lo;
+                        }
+        base += l == 0 ? BK16_L0_HALFS : BK16_L3_HALFS;
+    }
+}
+
 template <typename T>
 int upload(bk_engine* e, const std::vector<T>& h, const T** out) {
     void* d = nullptr;
@@ -127,6 +176,12 @@ int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, doub
     if ((rc = upload(e, bias, &np.bias))) return rc;
     if ((rc = upload(e, hw, &np.head_w))) return rc;
     if ((rc = upload(e, hb, &np.head_b))) return rc;
+    std::vector<_Float16> w16;
+    std::vector<float> b16;
+    pack_trunk16(t, w16, b16, np.cscale16);
+    np.inv_sa16 = 1.f / kSa16;
+    if ((rc = upload(e, w16, &np.wfrag16))) return rc;
+    if ((rc = upload(e, b16, &np.bias16))) return rc;
     return BK_OK;
 }
 
@@ -144,6 +199,8 @@ int alloc_slot(bk_engine* e, Slot& s) {
         HIP_TRY(e, hipHostMalloc((void**)&s.h_values, B * sizeof(float), hipHostMallocDefault));
         HIP_TRY(e, hipMalloc((void**)&s.d_values, B * sizeof(float)));
     }
+    HIP_TRY(e, hipMalloc((void**)&s.d_flag, sizeof(unsigned int)));
+    HIP_TRY(e, hipHostMalloc((void**)&s.h_flag, sizeof(unsigned int), hipHostMallocDefault));
     HIP_TRY(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     return BK_OK;
 }
@@ -157,6 +214,8 @@ void free_slot(Slot& s) {
     if (s.d_logits) (void)hipFree(s.d_logits);
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_values) (void)hipFree(s.d_values);
+    if (s.d_flag) (void)hipFree(s.d_flag);
+    if (s.h_flag) (void)hipHostFree(s.h_flag);
     if (s.done) (void)hipEventDestroy(s.done);
     s = Slot{};
 }
@@ -190,7 +249,7 @@ void drain_events(bk_engine* e) {
 
 // enqueue one kernel launch on `stream`; all pointers are device pointers
 int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, int want, float* d_logits,
-            float* d_probs, float* d_values, hipStream_t stream) {
+            float* d_probs, float* d_values, hipStream_t stream, int precision, unsigned int* d_flag) {
     if (B == 0) return BK_OK;
     bk_eval_args a{};
     a.net[0] = e->net[0];
@@ -218,7 +277,9 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         HIP_TRY(e, hipEventRecord(e->ev_ring[slot].first, stream));
         timed = true;
     }
-    HIP_TRY(e, bk_launch_leaf_eval(a, nb, stream));
+    a.overflow = d_flag;
+    HIP_TRY(e, precision == BK_PRECISION_F16X2 ? bk_launch_leaf_eval_f16(a, nb, stream)
+                                              : bk_launch_leaf_eval(a, nb, stream));
     if (timed) {
         HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
         e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
@@ -266,6 +327,8 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->max_batch = max_batch;
     e->has_policy = policy != nullptr;
     e->has_value = value != nullptr;
+    e->precision = BK_PRECISION_F16X2;  // default: fast path with automatic fp32 fallback on overflow
+    if (const char* pz = getenv("BK_PRECISION")) e->precision = std::string(pz) == "f32" ? BK_PRECISION_F32 : BK_PRECISION_F16X2;
     int rc = BK_OK;
     auto bail = [&](int code) {
         g_create_error = e->err;
@@ -315,6 +378,9 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
     e->dev_allocs.push_back(e->d_stamps);
 #endif
+    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, sizeof(unsigned int)));
+    e->dev_allocs.push_back(e->d_dev_flag);
+    TRY_CREATE(hipMemset(e->d_dev_flag, 0, sizeof(unsigned int)));
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);
     e->ev_ring.resize(512);
@@ -359,8 +425,13 @@ int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B
     if (B > 0) {
         std::memcpy(s->h_in, feats, (size_t)B * 2187 * esz);
         HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->stream));
-        rc = enqueue(e, s->d_in, feats_dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream);
+        *s->h_flag = 0;
+        if (e->precision == BK_PRECISION_F16X2) HIP_TRY(e, hipMemsetAsync(s->d_flag, 0, sizeof(unsigned int), e->stream));
+        rc = enqueue(e, s->d_in, feats_dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
+                     e->precision, s->d_flag);
         if (rc) return rc;
+        if (e->precision == BK_PRECISION_F16X2)
+            HIP_TRY(e, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
         if ((want & BK_WANT_LOGITS) && n_policy)
             HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
         if ((want & BK_WANT_PROBS) && n_policy)
@@ -373,6 +444,7 @@ int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B
     s->ticket = e->next_ticket++;
     s->B = B;
     s->n_policy = n_policy;
+    s->dtype = feats_dtype;
     s->want = want;
     s->logits = logits;
     s->probs = probs;
@@ -385,6 +457,21 @@ int bk_wait(bk_engine* e, int64_t ticket) {
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
         HIP_TRY(e, hipEventSynchronize(s.done));
+        if (s.B > 0 && *s.h_flag) {
+            // the f16x2 kernel clamped an activation: redo this request on the exact fp32 kernel
+            e->st.f16_overflow_fallbacks += 1;
+            int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, s.d_logits, s.d_probs, s.d_values, e->stream,
+                             BK_PRECISION_F32, nullptr);
+            if (rc) return rc;
+            if ((s.want & BK_WANT_LOGITS) && s.n_policy)
+                HIP_TRY(e, hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)s.n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+            if ((s.want & BK_WANT_PROBS) && s.n_policy)
+                HIP_TRY(e, hipMemcpyAsync(s.h_probs, s.d_probs, (size_t)s.n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+            if (s.want & BK_WANT_VALUE)
+                HIP_TRY(e, hipMemcpyAsync(s.h_values, s.d_values, (size_t)s.B * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            *s.h_flag = 0;
+        }
         if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_logits, (size_t)s.n_policy * 81 * 4);
         if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_probs, (size_t)s.n_policy * 81 * 4);
         if (s.want & BK_WANT_VALUE) std::memcpy(s.values, s.h_values, (size_t)s.B * 4);
@@ -429,8 +516,17 @@ int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, in
     // `stream` is used as given: NULL is HIP's null (legacy default) stream, which is also what
     // torch.cuda.current_stream() is unless the caller switched streams.
     return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
-                   static_cast<hipStream_t>(stream));
+                   static_cast<hipStream_t>(stream), e->precision, e->d_dev_flag);
 }
+
+int bk_engine_set_precision(bk_engine* e, int precision) {
+    if (!e) return BK_ERR_ARG;
+    if (precision != BK_PRECISION_F32 && precision != BK_PRECISION_F16X2) return fail(e, BK_ERR_ARG, "unknown precision");
+    e->precision = precision;
+    return BK_OK;
+}
+
+int bk_engine_get_precision(bk_engine* e) { return e ? e->precision : BK_ERR_ARG; }
 
 int bk_engine_set_profiling(bk_engine* e, int on) {
     if (!e) return BK_ERR_ARG;
@@ -452,6 +548,12 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
         HIP_TRY(e, hipSetDevice(e->device));
         HIP_TRY(e, hipDeviceSynchronize());
         drain_events(e);
+    }
+    if (e->d_dev_flag) {  // sticky flag of bk_eval_device*: the caller decides what to do about it
+        unsigned int f = 0;
+        HIP_TRY(e, hipSetDevice(e->device));
+        HIP_TRY(e, hipMemcpy(&f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
+        e->st.f16_device_overflow = f;
     }
     *out = e->st;
     return BK_OK;

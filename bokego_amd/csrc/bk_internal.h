@@ -11,6 +11,16 @@
 #define BK_WFRAG_FLOATS (BK_L0_FLOATS + 6 * BK_L3_FLOATS)
 #define BK_WFRAG_PAD_FLOATS 4096  // the B prefetch reads one block (4 groups, 16 KiB) past the last layer
 
+// f16x2 path: per layer [k16 step][cout tile (4)][piece hi/lo][lane (64)][8 halfs] = 4096 halfs per step
+#define BK16_L0_STEPS 52                      // 25 taps x 2 steps, zero-padded to a multiple of 4
+#define BK16_L0_HALFS (BK16_L0_STEPS * 4096)
+#define BK16_L3_HALFS (72 * 4096)             // 9 taps x 8 steps
+#define BK16_WFRAG_HALFS (BK16_L0_HALFS + 6 * BK16_L3_HALFS)
+#define BK16_WFRAG_PAD_HALFS (4 * 4096)       // the W prefetch runs 3 steps past the last layer
+
+#define BK_PRECISION_F32 0
+#define BK_PRECISION_F16X2 1
+
 #define BK_FEATS_F32_ 0
 #define BK_FEATS_U8_ 1
 
@@ -23,6 +33,11 @@ struct bk_net_params {
     const float* lin1_b;   // value: [64]
     const float* lin2_w;   // value: [64]
     float lin2_b;
+    // f16x2 path
+    const _Float16* wfrag16;  // BK16_WFRAG_HALFS (+pad): folded weights * 2^e_l as fp16 hi/lo fragments
+    const float* bias16;      // [7][128] sa * folded bias
+    float cscale16[7];        // sa_out / (sa_in * 2^e_l)
+    float inv_sa16;           // 1 / sa
 };
 
 struct bk_eval_args {
@@ -35,8 +50,10 @@ struct bk_eval_args {
     float* logits;         // [B][81] or null
     float* probs;          // [B][81] or null
     float* values;         // [B] or null
+    unsigned int* overflow;      // f16x2: set to 1 if an activation left the fp16 range (result unreliable)
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
 int bk_pick_nb(int B_policy, int B_value, int n_cu);
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
+hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -1,0 +1,397 @@
+// bk_kernels_f16.hip -- split-precision ("f16x2") variant of the fused leaf-evaluation kernel.
+//
+// Same fusion as bk_kernels.hip (NB boards of one net stay in LDS through all 7 conv layers and
+// the head), but the convolutions run on v_mfma_f32_32x32x16_f16, which issues 16x the MACs per
+// cycle of the fp32 matrix instruction.  fp32 accuracy is kept by splitting every operand into
+// an fp16 pair:  x = (x_hi + x_lo) / s  with  x_hi = fp16(s x),  x_lo = fp16(s x - x_hi)
+// (22 significant bits, s a power of two), and accumulating, in fp32 inside the matrix unit,
+//      w_hi x_hi + w_lo x_hi + w_hi x_lo        (the w_lo x_lo term is < 2^-22 and dropped)
+// = 3 MFMAs of 32 cycles per 16-deep K step instead of 8 fp32 MFMAs of 64 cycles.
+// An offline float64 emulation over the 536 golden positions puts the logit
+// error this split adds at <= 1e-5, below the 5.7e-5 of the exact-fp32 kernel's summation order.
+//
+// Orientation is transposed w.r.t. bk_kernels.hip: the weights are the MFMA "A" operand (rows =
+// couts) and the activations the "B" operand (columns = positions), so a lane's accumulator
+// registers hold 4 CONSECUTIVE couts of ONE position and the epilogue writes them as one 8-byte
+// hi and one 8-byte lo store.
+//
+// LDS layout: 512 B per position as before, now [hi plane: 16 groups x 8 fp16][lo plane: same];
+// 16-byte groups XOR-swizzled by the position within each plane; lo = hi address + 256.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bk_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef BK_EXP
+#define BK_EXP 0
+#endif
+#ifdef BK_STAMPS
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long _t;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+        if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (k)] = _t;      \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+namespace {
+
+__device__ __forceinline__ int pos3(int b, int y, int x) { return (10 * b + 1 + y) * 10 + x + 1; }
+__device__ __forceinline__ int pos5(int b, int y, int x) { return (11 * b + 2 + y) * 11 + x + 2; }
+
+template <int NB>
+struct Geo {
+    static constexpr int MT = (81 * NB + 31) / 32;
+    static constexpr int NPOS = 100 * NB + 11;
+    static constexpr int NP0 = 121 * NB + 24;
+    static constexpr int WM = (MT % 2 == 0) ? 2 : 1;  // wave grid over [position tiles x cout tiles]
+    static constexpr int WN = 4 / WM;
+    static constexpr int NT = 4 / WN;
+    static constexpr int MTW = MT / WM;
+    static constexpr int DUMMY_BYTES = 2048;  // 64 x 16 B slots for the hi store, the lo store lands 256 B further
+    static constexpr int HS_FLOATS = NB * 96;
+    static constexpr int LDS_BYTES = NPOS * 512 + DUMMY_BYTES + HS_FLOATS * 4;
+};
+
+// One conv layer for one wave.  acc[mt][nt]: 32 couts (rows) x 32 positions (columns).
+// wl: the layer's fp16 fragments [k16 step][cout tile (4)][piece hi/lo][lane][8], 8 KiB per step.
+template <int NB, bool FIRST>
+__device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* __restrict__ wl,
+                                             f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
+    constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
+    constexpr int KW = FIRST ? 5 : 3;
+    constexpr int TAPS = KW * KW;
+    constexpr int S = FIRST ? 2 : 8;                      // k16 steps per tap (32 / 128 input channels)
+    constexpr int NSTEPS = FIRST ? BK16_L0_STEPS : TAPS * S;  // layer 0 is zero-padded to a multiple of 4
+    constexpr int ROWB = FIRST ? 128 : 512;               // bytes per position
+    constexpr int LO = FIRST ? 64 : 256;                  // hi plane -> lo plane
+    const int h = lane >> 5, l32 = lane & 31;
+
+    int pbase[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        int r = (wm * MTW + mt) * 32 + l32;
+        if (r >= 81 * NB) r = 0;  // padding columns compute from a valid address; never stored
+        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
+        pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    // weights: wave-uniform base + lane offset (scalar pointer arithmetic per step)
+    const _Float16* wv = wl + (wn * NT) * 1024;  // 2 pieces x 512 halfs per cout tile
+    const int lane8 = lane * 8;
+    auto load_w = [&](f16x8 (&W)[NT][2], int ks) {
+        const _Float16* wb = wv + (size_t)ks * 4096;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+                W[nt][pc] = *reinterpret_cast<const f16x8*>(wb + (nt * 2 + pc) * 512 + lane8);
+    };
+
+    // activations: byte address = ab + ((group<<4) ^ (key<<4)); lo plane at +LO (immediate)
+    int ab[MTW], swb[MTW];
+    auto tap_setup = [&](int t) {
+        t = t < TAPS ? t : TAPS - 1;  // the zero-weight padding steps of layer 0 re-read the last tap
+        const int ky = t / KW, kx = t - ky * KW;
+        const int off = FIRST ? (ky - 2) * 11 + (kx - 2) : (ky - 1) * 10 + (kx - 1);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int pa = pbase[mt] + off;
+            ab[mt] = pa * ROWB;
+            swb[mt] = (FIRST ? ((pa >> 1) & 3) : (pa & 15)) << 4;
+        }
+    };
+    auto read_x = [&](f16x8 (&X)[MTW][2], int s) {
+        const int gb = (2 * s + h) << 4;  // this lane half's 8-channel group
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const char* p = actb + (ab[mt] + (gb ^ swb[mt]));
+            X[mt][0] = *reinterpret_cast<const f16x8*>(p);
+            X[mt][1] = *reinterpret_cast<const f16x8*>(p + LO);
+        }
+    };
+
+    f16x8 X0[MTW][2], X1[MTW][2];
+    f16x8 W0[NT][2], W1[NT][2], W2[NT][2], W3[NT][2];
+
+    auto mma = [&](const f16x8 (&X)[MTW][2], const f16x8 (&W)[NT][2]) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], X[mt][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][1], acc[mt][nt], 0, 0, 0);
+            }
+    };
+
+    // step ks: X(ks+1) is read from LDS and W(ks+3) fetched from L2 while step ks's 24 MFMAs run
+    auto step = [&](int ks, const f16x8 (&Xc)[MTW][2], f16x8 (&Xn)[MTW][2], const f16x8 (&Wc)[NT][2],
+                    f16x8 (&Wn3)[NT][2], bool may_cross) {
+#if BK_EXP == 2   // timing experiment: no weight traffic in the loop (results are wrong)
+        (void)Wn3;
+#else
+        load_w(Wn3, ks + 3);
+#endif
+        const int kn = ks + 1;
+        if (may_cross && (kn % S) == 0) tap_setup(kn / S);
+#if BK_EXP == 1   // timing experiment: no LDS reads in the loop (results are wrong)
+        (void)Xn;
+#else
+        read_x(Xn, kn % S);
+#endif
+        mma(Xc, Wc);
+        // Issue order inside the step: the matrix pipe must never wait for a burst of loads, so
+        // the 2*MTW LDS reads and 2*NT weight loads are dealt out between the MFMAs (3 MFMAs = 96
+        // cycles of cover per LDS read).  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read, 0x2 VALU.
+#pragma unroll
+        for (int i = 0; i < 2 * MTW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (3 * MTW * NT) / (2 * MTW), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    load_w(W0, 0);
+    load_w(W1, 1);
+    load_w(W2, 2);
+    tap_setup(0);
+    read_x(X0, 0);
+#pragma unroll 1
+    for (int ks = 0; ks < NSTEPS; ks += 4) {
+        step(ks + 0, X0, X1, W0, W3, S < 2);
+        step(ks + 1, X1, X0, W1, W0, S <= 2);
+        step(ks + 2, X0, X1, W2, W1, S < 2);
+        step(ks + 3, X1, X0, W3, W2, true);
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_args a) {
+    using G = Geo<NB>;
+    constexpr int MTW = G::MTW, NT = G::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char* actb = smem16;
+    const int dummy_addr = G::NPOS * 512 + (threadIdx.x & 63) * 16;
+    float* hs = reinterpret_cast<float*>(smem16 + G::NPOS * 512 + G::DUMMY_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+
+    int net, task;
+    const int bid = blockIdx.x;
+    const int m4 = min(a.tasks_p, a.tasks_v) & ~3;
+    if (bid < 2 * m4) {
+        net = (bid >> 2) & 1;
+        task = ((bid >> 3) << 2) | (bid & 3);
+    } else {
+        const int r = bid - 2 * m4;
+        if (r < a.tasks_p - m4) { net = 0; task = m4 + r; }
+        else { net = 1; task = m4 + r - (a.tasks_p - m4); }
+    }
+    const bk_net_params& P = a.net[net];
+    const int b0 = task * NB;
+    const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
+
+    STAMP(0);
+    // ---- stage the feature planes as fp16 hi/lo: NCHW global -> [pos][hi 4x8 | lo 4x8] ----
+    for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int e = tid; e < nb * 2187; e += 256) {
+        const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
+        const float v = a.feats_dtype == BK_FEATS_F32_ ? static_cast<const float*>(a.feats)[(size_t)b0 * 2187 + e]
+                                                       : (float)static_cast<const uint8_t*>(a.feats)[(size_t)b0 * 2187 + e];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int p = pos5(b, y, x);
+        char* d = actb + p * 128 + ((((c >> 3) ^ ((p >> 1) & 3))) << 4) + 2 * (c & 7);
+        *reinterpret_cast<_Float16*>(d) = hi;
+        *reinterpret_cast<_Float16*>(d + 64) = lo;
+    }
+    __syncthreads();
+
+    STAMP(1);
+    f32x16 acc[MTW][NT];
+    const int wm = wave / G::WN, wn = wave - wm * G::WN;
+
+    // epilogue: acc register 4q+j of (mt, nt) = cout 32*(wn*NT+nt) + 8q + 4h + j at this lane's position
+    float umax = 0.f;  // largest pre-clamp activation seen by this lane (inf if anything overflowed)
+    auto store = [&](int L) {
+        const float cs = P.cscale16[L];                 // sa_out / (sa_in * sw_L): a power of two
+        const float* bias = P.bias16 + L * 128;         // sa_out * folded bias
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int r = (wm * MTW + mt) * 32 + l32;
+            const int b = r / 81, q81 = r - 81 * b, y = q81 / 9, x = q81 - 9 * y;
+            const int p = pos3(b, y, x);
+            const int rowb = r < 81 * NB ? p * 512 : -1;
+            const int key = (p & 15) << 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = 32 * (wn * NT + nt) + 8 * q + 4 * h;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u = fmaf(acc[mt][nt][4 * q + j], cs, bv[j]);
+                        v[j] = __builtin_amdgcn_fmed3f(u, 0.f, 65504.f);  // ReLU + fp16 range
+                        umax = fmaxf(umax, u);
+                    }
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hi[j] = (_Float16)v[j];
+                        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+                    }
+                    const int addr = rowb >= 0 ? rowb + ((((c0 >> 3) << 4) ^ key) | (8 * h)) : dummy_addr;
+                    *reinterpret_cast<f16x4*>(actb + addr) = hi;
+                    *reinterpret_cast<f16x4*>(actb + addr + 256) = lo;
+                }
+        }
+    };
+
+    // ---- layer 0: 5x5, 27(32) -> 128 ----
+    conv_layer16<NB, true>(actb, P.wfrag16, acc, lane, wm, wn);
+    STAMP(2);
+    __syncthreads();
+    for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    STAMP(3);
+    store(0);
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+
+    // ---- layers 1..6: 3x3, 128 -> 128, in place ----
+#pragma unroll 1
+    for (int L = 1; L < 7; ++L) {
+        conv_layer16<NB, false>(actb, P.wfrag16 + BK16_L0_HALFS + (size_t)(L - 1) * BK16_L3_HALFS, acc, lane, wm, wn);
+        STAMP(2 + 4 * L);
+        __syncthreads();
+        STAMP(3 + 4 * L);
+        store(L);
+        STAMP(4 + 4 * L);
+        __syncthreads();
+        STAMP(5 + 4 * L);
+    }
+
+    // an activation beyond the fp16 range was clamped: tell the host, which re-runs the batch in fp32
+    if (__any(!(umax < 65504.f)) && lane == 0 && a.overflow) atomicOr(a.overflow, 1u);
+
+    // ---- heads: wave w handles board w (activations = (hi + lo) * inv_sa) ----
+    if (wave < nb) {
+        float s[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = lane + 64 * k;
+            float d = 0.f;
+            if (q < 81) {
+                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x);
+                const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
+#pragma unroll 4
+                for (int g = 0; g < 16; ++g) {
+                    const char* src = actb + p * 512 + ((g ^ (p & 15)) << 4);
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(src);
+                    const f16x8 vl = *reinterpret_cast<const f16x8*>(src + 256);
+                    const f32x4 w0 = hw[2 * g], w1 = hw[2 * g + 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        d += ((float)vh[j] + (float)vl[j]) * w0[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        d += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[j];
+                    }
+                }
+                d = d * P.inv_sa16 + P.head_b[q];
+            }
+            s[k] = d;
+        }
+        const int bg = b0 + wave;
+        if (net == 0) {
+            float m = fmaxf(s[0], (lane + 64 < 81) ? s[1] : -INFINITY);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float e0 = expf(s[0] - m);
+            const float e1 = (lane + 64 < 81) ? expf(s[1] - m) : 0.f;
+            float sum = e0 + e1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = 1.f / sum;
+            if (a.logits) {
+                a.logits[(size_t)bg * 81 + lane] = s[0];
+                if (lane + 64 < 81) a.logits[(size_t)bg * 81 + lane + 64] = s[1];
+            }
+            if (a.probs) {
+                a.probs[(size_t)bg * 81 + lane] = e0 * inv;
+                if (lane + 64 < 81) a.probs[(size_t)bg * 81 + lane + 64] = e1 * inv;
+            }
+        } else {
+            float* hv = hs + wave * 96;
+            hv[lane] = fmaxf(s[0], 0.f);
+            if (lane + 64 < 81) hv[lane + 64] = fmaxf(s[1], 0.f);
+            __builtin_amdgcn_wave_barrier();
+            float z = P.lin1_b[lane];
+#pragma unroll 9
+            for (int q = 0; q < 81; ++q) z += P.lin1_wt[q * 64 + lane] * hv[q];
+            z = fmaxf(z, 0.f);
+            float v = z * P.lin2_w[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            v += P.lin2_b;
+            if (lane == 0 && a.values) a.values[bg] = tanhf(v);
+        }
+    }
+    STAMP(30);
+}
+
+template <int NB>
+hipError_t launch16_nb(const bk_eval_args& a, hipStream_t stream) {
+    static bool attr_set = false;
+    auto kern = bk_leaf_eval_f16_kernel<NB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NB>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    bk_eval_args args = a;
+    args.tasks_p = (a.B_policy + NB - 1) / NB;
+    args.tasks_v = (a.B_value + NB - 1) / NB;
+    const int grid = args.tasks_p + args.tasks_v;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Geo<NB>::LDS_BYTES, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream) {
+    switch (nb) {
+        case 1: return launch16_nb<1>(a, stream);
+        case 2: return launch16_nb<2>(a, stream);
+        default: return launch16_nb<3>(a, stream);
+    }
+}

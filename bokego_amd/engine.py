@@ -54,7 +54,7 @@ _HEAD_KEYS = (("bn_w", "bn.weight", 1), ("bn_b", "bn.bias", 1), ("bn_mean", "bn.
 class LeafEngine:
     """policy_sd / value_sd: mappings with the reference state_dict names (torch tensors or arrays)."""
 
-    def __init__(self, policy_sd=None, value_sd=None, device_id=0, max_batch=4096):
+    def __init__(self, policy_sd=None, value_sd=None, device_id=0, max_batch=4096, precision=None):
         if policy_sd is None and value_sd is None:
             raise TypeError("LeafEngine needs policy and/or value weights")
         lib = L.load()
@@ -85,6 +85,18 @@ class LeafEngine:
         self.device_id, self.max_batch = int(device_id), int(max_batch)
         self.has_policy, self.has_value = policy_sd is not None, value_sd is not None
         self._pending = {}
+        if precision is not None:
+            self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """'f32': exact fp32 MFMA; 'f16x2': fp16 hi/lo split operands, fp32 accumulation (faster)."""
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(L.PRECISIONS)}")
+        self._check(self._lib.bk_engine_set_precision(self._h, L.PRECISIONS[precision]))
+
+    @property
+    def precision(self):
+        return {v: k for k, v in L.PRECISIONS.items()}[self._lib.bk_engine_get_precision(self._h)]
 
     # -- helpers ---------------------------------------------------------------------------
     def _check(self, rc):

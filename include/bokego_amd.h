@@ -86,6 +86,8 @@ typedef struct bk_stats_t {
     double kernel_ms_sum;    /* sum of HIP-event kernel durations (profiling on) */
     uint64_t kernel_ms_count;
     double last_kernel_ms;
+    uint64_t f16_overflow_fallbacks; /* host-buffer requests redone in fp32 because an activation left the fp16 range */
+    uint64_t f16_device_overflow;    /* bk_eval_device*: non-zero if that ever happened (results of that call unreliable) */
 } bk_stats_t;
 
 int bk_abi_version(void);
@@ -137,6 +139,22 @@ int64_t bk_submit_prefix(bk_engine *e, const void *feats, int feats_dtype, int B
                          float *logits, float *probs, float *values);
 int bk_eval_device_prefix(bk_engine *e, const void *d_feats, int feats_dtype, int B, int n_policy, int want,
                           float *d_logits, float *d_probs, float *d_values, void *stream);
+
+/*
+ * Arithmetic of the conv stacks (new; the reference computes in torch fp32):
+ *   BK_PRECISION_FP32   v_mfma_f32_32x32x2_f32, exact fp32 products and fp32 accumulation
+ *   BK_PRECISION_F16X2  (default) every operand split into an fp16 hi/lo pair (22 significant bits),
+ *                       three v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation; ~fp32 accuracy
+ *                       (inside the 1e-4 parity budget), several times the throughput.  If an
+ *                       activation leaves the fp16 range (|x| >= 4094) the kernel raises a flag
+ *                       and bk_wait() transparently redoes that request on the fp32 kernel;
+ *                       bk_eval_device* only records it in bk_stats().f16_device_overflow.
+ * The environment variable BK_PRECISION=f32|f16x2 sets the default of new engines.
+ */
+#define BK_PRECISION_FP32 0
+#define BK_PRECISION_F16X2 1
+int bk_engine_set_precision(bk_engine *e, int precision);
+int bk_engine_get_precision(bk_engine *e);
 
 int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every kernel launch */
 int bk_stats(bk_engine *e, bk_stats_t *out);

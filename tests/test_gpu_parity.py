@@ -20,10 +20,12 @@ def weights():
     return load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
 
 
-@pytest.fixture(scope="module")
-def engine(weights):
+@pytest.fixture(scope="module", params=["f32", "f16x2"])
+def engine(weights, request):
+    """every parity test runs on both arithmetic modes of the conv stacks (same tolerances)"""
     from bokego_amd.engine import LeafEngine
-    e = LeafEngine(weights[0], weights[1], device_id=0, max_batch=4096)
+    e = LeafEngine(weights[0], weights[1], device_id=0, max_batch=4096, precision=request.param)
+    assert e.precision == request.param
     yield e
     e.close()
 
@@ -147,3 +149,23 @@ def test_device_resident_path(engine, gold):
     torch.cuda.synchronize()
     _check({k: o[k].cpu().numpy() for k in ("logits", "probs", "value")},
            n["logits_b1"][:300], n["probs_b1"][:300], n["values_b1"][:300])
+
+
+def test_f16x2_overflow_falls_back_to_fp32(weights, oracle):
+    """Activations beyond the fp16 range: the f16x2 kernel raises its flag and the engine redoes the
+    request on the exact fp32 kernel, so the caller still gets fp32-quality results."""
+    from bokego_amd.engine import LeafEngine
+    rng = np.random.default_rng(3)
+    x = (rng.integers(0, 8, size=(5, 27, 9, 9)) * 4000.0).astype(np.float32)   # absurdly large planes
+    fast = LeafEngine(weights[0], weights[1], max_batch=8, precision="f16x2")
+    exact = LeafEngine(weights[0], weights[1], max_batch=8, precision="f32")
+    a = fast.eval(x, logits=True, probs=False, value=True)
+    b = exact.eval(x, logits=True, probs=False, value=True)
+    assert fast.stats()["f16_overflow_fallbacks"] == 1 and exact.stats()["f16_overflow_fallbacks"] == 0
+    assert np.array_equal(a["logits"], b["logits"]) and np.array_equal(a["value"], b["value"])
+    lg = oracle[0](x)
+    assert np.abs(a["logits"] - lg).max() <= 2e-6 * np.abs(lg).max()
+    # ordinary inputs do not trigger it
+    fast.eval((x / 4000.0).astype(np.float32), logits=True, probs=False, value=True)
+    assert fast.stats()["f16_overflow_fallbacks"] == 1
+    fast.close(); exact.close()

@@ -65,7 +65,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     if a:
         o.write(f"LDS: bank-conflict cycles / active cycles = {c/a*100:.1f} %; LDS active = {a/256/(g/8)*100:.1f} % of CU time\n")
 fs, ws = pmc.get("FETCH_SIZE", (0, 0))[0], pmc.get("WRITE_SIZE", (0, 0))[0]
-json.dump({"tag": tag, "kernel": kern["Name"], "rocprof_avg_kernel_ms": avg_ms, "batch": B,
+json.dump({"tag": tag, "precision": bench["config"].get("precision"), "kernel": kern["Name"], "rocprof_avg_kernel_ms": avg_ms, "batch": B,
            "counters": {k: v[0] for k, v in pmc.items()},
            "hbm_traffic_bytes_per_launch": (2 * fs + ws) * 1024 if fs else None,
            "traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction"},
