@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "bk_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +66,39 @@ struct Geo {
     static constexpr int LDS_BYTES = NPOS * 512 + DUMMY_BYTES + HS_FLOATS * 4;
 };
 
+// Flat row index r of the workgroup's GEMM -> board point.  NB == 3 uses a y-major order so that
+// tile 0 holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding
+// rows each, tiles 1..6 the 189 points with y in 1..7): a 3x3 tap with dy=-1 reads only zero halo
+// for tile 0 and one with dy=+1 only zero halo for tile 7, so those MFMAs are skipped.
+template <int NB>
+__device__ __forceinline__ bool row_decode(int r, int& b, int& y, int& x) {
+    bool valid;
+    if (NB == 3) {
+        if (r < 32) { valid = r < 27; b = r / 9; y = 0; x = r - 9 * b; }
+        else if (r < 224) { const int i = r - 32; valid = i < 189; b = i / 63; const int j = i - 63 * b; y = 1 + j / 9; x = j - 9 * (y - 1); }
+        else { const int i = r - 224; valid = i < 27; b = i / 9; y = 8; x = i - 9 * b; }
+    } else {
+        valid = r < 81 * NB;
+        b = r / 81;
+        const int q = r - 81 * b;
+        y = q / 9;
+        x = q - 9 * y;
+    }
+    if (!valid) { b = 0; y = NB == 3 ? 4 : 0; x = 0; }  // padding rows compute from a valid address; never stored
+    return valid;
+}
+
+// Issue order inside one K step: NMFMA matrix instructions with NREADS LDS reads (2 address VALU
+// each) and NLOADS weight loads dealt out between them, so the matrix pipe never waits for a
+// burst of loads.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read, 0x2 VALU.
+template <int NMFMA, int NREADS, int NLOADS, int... I>
+__device__ __forceinline__ void sched_pattern(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NREADS + (I < NMFMA % NREADS ? 1 : 0), 0),
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0), __builtin_amdgcn_sched_group_barrier(0x100, 1, 0),
+      __builtin_amdgcn_sched_group_barrier(0x020, I < NLOADS ? 1 : 0, 0)),
+     ...);
+}
+
 // One conv layer for one wave.  acc[mt][nt]: 32 couts (rows) x 32 positions (columns).
 // wl: the layer's fp16 fragments [k16 step][cout tile (4)][piece hi/lo][lane][8], 8 KiB per step.
 template <int NB, bool FIRST>
@@ -77,13 +113,13 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
     constexpr int LO = FIRST ? 64 : 256;                  // hi plane -> lo plane
     const int h = lane >> 5, l32 = lane & 31;
 
-    int pbase[MTW];
+    int pbase[MTW], rrow[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        int r = (wm * MTW + mt) * 32 + l32;
-        if (r >= 81 * NB) r = 0;  // padding columns compute from a valid address; never stored
-        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
+        int b, y, x;
+        row_decode<NB>((wm * MTW + mt) * 32 + l32, b, y, x);
         pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
+        rrow[mt] = 81 * b + 9 * y + x;
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -114,7 +150,10 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
         for (int mt = 0; mt < MTW; ++mt) {
             const int pa = pbase[mt] + off;
             ab[mt] = pa * ROWB;
-            swb[mt] = (FIRST ? ((pa >> 1) & 3) : (pa & 15)) << 4;
+            // swizzle key of the position being read = low bits of ITS flat row index r + 9dy + dx
+            // (the writer's key): the 16 lanes of a ds_read_b128 group then hit 16 distinct slots.
+            // Out-of-board neighbours land in all-zero halo rows, where any key reads zeros.
+            swb[mt] = (FIRST ? ((pa >> 1) & 3) : ((rrow[mt] + 9 * (ky - 1) + (kx - 1)) & 15)) << 4;
         }
     };
     auto read_x = [&](f16x8 (&X)[MTW][2], int s) {
@@ -130,9 +169,10 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
     f16x8 X0[MTW][2], X1[MTW][2];
     f16x8 W0[NT][2], W1[NT][2], W2[NT][2], W3[NT][2];
 
-    auto mma = [&](const f16x8 (&X)[MTW][2], const f16x8 (&W)[NT][2]) {
+    // MLO..MHI: the position tiles of this wave that take part (tap skipping, see row_decode)
+    auto mma = [&](auto MLO, auto MHI, const f16x8 (&X)[MTW][2], const f16x8 (&W)[NT][2]) {
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = decltype(MLO)::value; mt < decltype(MHI)::value; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][0], acc[mt][nt], 0, 0, 0);
@@ -141,9 +181,10 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
             }
     };
 
-    // step ks: X(ks+1) is read from LDS and W(ks+3) fetched from L2 while step ks's 24 MFMAs run
-    auto step = [&](int ks, const f16x8 (&Xc)[MTW][2], f16x8 (&Xn)[MTW][2], const f16x8 (&Wc)[NT][2],
-                    f16x8 (&Wn3)[NT][2], bool may_cross) {
+    // step ks: X(ks+1) is read from LDS and W(ks+3) fetched from L2 while step ks's MFMAs run
+    auto step = [&](auto MLO, auto MHI, int ks, const f16x8 (&Xc)[MTW][2], f16x8 (&Xn)[MTW][2],
+                    const f16x8 (&Wc)[NT][2], f16x8 (&Wn3)[NT][2], bool may_cross) {
+        constexpr int NMFMA = 3 * (decltype(MHI)::value - decltype(MLO)::value) * NT;
 #if BK_EXP == 2   // timing experiment: no weight traffic in the loop (results are wrong)
         (void)Wn3;
 #else
@@ -156,18 +197,20 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
 #else
         read_x(Xn, kn % S);
 #endif
-        mma(Xc, Wc);
-        // Issue order inside the step: the matrix pipe must never wait for a burst of loads, so
-        // the 2*MTW LDS reads and 2*NT weight loads are dealt out between the MFMAs (3 MFMAs = 96
-        // cycles of cover per LDS read).  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read, 0x2 VALU.
-#pragma unroll
-        for (int i = 0; i < 2 * MTW; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, (3 * MTW * NT) / (2 * MTW), 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
+        mma(MLO, MHI, Xc, Wc);
+        sched_pattern<NMFMA, 2 * MTW, 2 * NT>(std::make_integer_sequence<int, 2 * MTW>{});
         __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // steps [k0, k1) (multiples of 4) with one tile range; the operand pipelines run across calls
+    auto run = [&](auto MLO, auto MHI, int k0, int k1) {
+#pragma unroll 1
+        for (int ks = k0; ks < k1; ks += 4) {
+            step(MLO, MHI, ks + 0, X0, X1, W0, W3, S < 2);
+            step(MLO, MHI, ks + 1, X1, X0, W1, W0, S <= 2);
+            step(MLO, MHI, ks + 2, X0, X1, W2, W1, S < 2);
+            step(MLO, MHI, ks + 3, X1, X0, W3, W2, true);
+        }
     };
 
     load_w(W0, 0);
@@ -175,12 +218,19 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
     load_w(W2, 2);
     tap_setup(0);
     read_x(X0, 0);
-#pragma unroll 1
-    for (int ks = 0; ks < NSTEPS; ks += 4) {
-        step(ks + 0, X0, X1, W0, W3, S < 2);
-        step(ks + 1, X1, X0, W1, W0, S <= 2);
-        step(ks + 2, X0, X1, W2, W1, S < 2);
-        step(ks + 3, X1, X0, W3, W2, true);
+    using I0 = std::integral_constant<int, 0>;
+    using IM = std::integral_constant<int, MTW>;
+    if constexpr (NB == 3 && !FIRST) {
+        // taps ky=0 are steps [0,24), ky=1 [24,48), ky=2 [48,72)
+        if (wm == 0) {
+            run(std::integral_constant<int, 1>{}, IM{}, 0, 24);   // tile 0 = y=0 points: dy=-1 is all halo
+            run(I0{}, IM{}, 24, 72);
+        } else {
+            run(I0{}, IM{}, 0, 48);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 48, 72);  // tile 7 = y=8 points: dy=+1 is all halo
+        }
+    } else {
+        run(I0{}, IM{}, 0, NSTEPS);
     }
 }
 
@@ -217,16 +267,35 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     // ---- stage the feature planes as fp16 hi/lo: NCHW global -> [pos][hi 4x8 | lo 4x8] ----
     for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    for (int e = tid; e < nb * 2187; e += 256) {
-        const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-        const float v = a.feats_dtype == BK_FEATS_F32_ ? static_cast<const float*>(a.feats)[(size_t)b0 * 2187 + e]
-                                                       : (float)static_cast<const uint8_t*>(a.feats)[(size_t)b0 * 2187 + e];
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+    if (tid < nb * 81) {
+        // one thread per position: 27 channel loads (coalesced across threads: consecutive points of a
+        // plane), split into fp16 hi/lo, stored as 4 groups x (16 B hi + 16 B lo)
+        const int b = tid / 81, q = tid - 81 * b, y = q / 9, x = q - 9 * y;
         const int p = pos5(b, y, x);
-        char* d = actb + p * 128 + ((((c >> 3) ^ ((p >> 1) & 3))) << 4) + 2 * (c & 7);
-        *reinterpret_cast<_Float16*>(d) = hi;
-        *reinterpret_cast<_Float16*>(d + 64) = lo;
+        float v[32];
+        if (a.feats_dtype == BK_FEATS_F32_) {
+            const float* src = static_cast<const float*>(a.feats) + (size_t)(b0 + b) * 2187 + q;
+#pragma unroll
+            for (int c = 0; c < 27; ++c) v[c] = src[c * 81];
+        } else {
+            const uint8_t* src = static_cast<const uint8_t*>(a.feats) + (size_t)(b0 + b) * 2187 + q;
+#pragma unroll
+            for (int c = 0; c < 27; ++c) v[c] = (float)src[c * 81];
+        }
+#pragma unroll
+        for (int c = 27; c < 32; ++c) v[c] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = (_Float16)v[8 * g + j];
+                lo[j] = (_Float16)(v[8 * g + j] - (float)hi[j]);
+            }
+            char* d = actb + p * 128 + ((g ^ ((p >> 1) & 3)) << 4);
+            *reinterpret_cast<f16x8*>(d) = hi;
+            *reinterpret_cast<f16x8*>(d + 64) = lo;
+        }
     }
     __syncthreads();
 
@@ -241,11 +310,11 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
         const float* bias = P.bias16 + L * 128;         // sa_out * folded bias
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            const int r = (wm * MTW + mt) * 32 + l32;
-            const int b = r / 81, q81 = r - 81 * b, y = q81 / 9, x = q81 - 9 * y;
+            int b, y, x;
+            const bool valid = row_decode<NB>((wm * MTW + mt) * 32 + l32, b, y, x);
             const int p = pos3(b, y, x);
-            const int rowb = r < 81 * NB ? p * 512 : -1;
-            const int key = (p & 15) << 4;
+            const int rowb = valid ? p * 512 : -1;
+            const int key = ((81 * b + 9 * y + x) & 15) << 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -308,11 +377,11 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
             const int q = lane + 64 * k;
             float d = 0.f;
             if (q < 81) {
-                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x);
+                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x), key = (81 * wave + q) & 15;
                 const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
 #pragma unroll 4
                 for (int g = 0; g < 16; ++g) {
-                    const char* src = actb + p * 512 + ((g ^ (p & 15)) << 4);
+                    const char* src = actb + p * 512 + ((g ^ key) << 4);
                     const f16x8 vh = *reinterpret_cast<const f16x8*>(src);
                     const f16x8 vl = *reinterpret_cast<const f16x8*>(src + 256);
                     const f32x4 w0 = hw[2 * g], w1 = hw[2 * g + 1];
