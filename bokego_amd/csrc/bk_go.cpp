@@ -279,8 +279,8 @@ void bk_pos_liberties(bk_pos* p, uint8_t out[81]) {
     std::memcpy(out, p->libs, NN);
 }
 
-float bk_pos_score(const bk_pos* p, float komi) {
-    // Tromp-Taylor area: stones + empty regions bordered by one colour only (go.py:202-218)
+float bk_pos_area_score(const bk_pos* p, float komi) {
+    // Tromp-Taylor area: stones + empty regions bordered by one colour only
     int black = 0, white = 0;
     uint8_t seen[NN] = {0};
     for (int s = 0; s < NN; ++s) {
@@ -305,6 +305,50 @@ float bk_pos_score(const bk_pos* p, float komi) {
             if (tb && !tw) black += size;
             else if (tw && !tb) white += size;
         }
+    }
+    return (float)black - ((float)white + komi);
+}
+
+float bk_pos_score(const bk_pos* p, float komi) {
+    // Game.score (go.py:202-218) restated literally, including what it does beyond Tromp-Taylor:
+    // regions are processed in board order on a board that is repainted as it goes, and a
+    // region's BORDER stones are repainted too -- with '?' when the region touches both colours,
+    // so stones next to neutral points drop out of the count and later regions see the '?'.
+    enum { Q = 3 };
+    int8_t b[NN];
+    std::memcpy(b, p->board, NN);
+    for (;;) {
+        int first = -1;
+        for (int s = 0; s < NN; ++s)
+            if (b[s] == BK_EMPTY) { first = s; break; }
+        if (first < 0) break;
+        uint8_t in_region[NN] = {0}, is_border[NN] = {0};
+        int8_t stack[NN];
+        int sp = 0;
+        stack[sp++] = (int8_t)first;
+        in_region[first] = 1;
+        bool tb = false, tw = false;
+        while (sp) {
+            const int q = stack[--sp];
+            for (int k = 0; k < T.nn[q]; ++k) {
+                const int t = T.nbr[q][k];
+                if (b[t] == BK_EMPTY) {
+                    if (!in_region[t]) { in_region[t] = 1; stack[sp++] = (int8_t)t; }
+                } else {
+                    is_border[t] = 1;
+                    if (b[t] == BK_BLACK) tb = true;
+                    else if (b[t] == BK_WHITE) tw = true;
+                }
+            }
+        }
+        const int8_t paint = (tb && !tw) ? BK_BLACK : (tw && !tb) ? BK_WHITE : (int8_t)Q;
+        for (int s = 0; s < NN; ++s)
+            if (in_region[s] || is_border[s]) b[s] = paint;
+    }
+    int black = 0, white = 0;
+    for (int s = 0; s < NN; ++s) {
+        black += b[s] == BK_BLACK;
+        white += b[s] == BK_WHITE;
     }
     return (float)black - ((float)white + komi);
 }

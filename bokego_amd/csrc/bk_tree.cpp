@@ -246,7 +246,7 @@ struct Game {
                 case S_ROOT_READY:
                     add_noise(root);
                     if (nodes[root].terminal || nodes[root].n_kids == 0) {
-                        final_score = bk_pos_score(&nodes[root].pos, prm.komi);
+                        final_score = bk_pos_area_score(&nodes[root].pos, prm.komi);
                         state = S_DONE;
                         break;
                     }

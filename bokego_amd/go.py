@@ -41,6 +41,7 @@ GO_SYMBOLS = {
     "bk_pos_legal_moves": (ctypes.c_int, [_PP, _U8P]),
     "bk_pos_liberties": (None, [_PP, _U8P]),
     "bk_pos_score": (ctypes.c_float, [_PP, ctypes.c_float]),
+    "bk_pos_area_score": (ctypes.c_float, [_PP, ctypes.c_float]),
     "bk_pos_eye_like": (ctypes.c_int, [_PP, ctypes.c_int, ctypes.c_int]),
     "bk_pos_features_u8": (None, [_PP, ctypes.c_void_p, ctypes.c_int]),
     "bk_pos_features_f32": (None, [_PP, ctypes.c_void_p, ctypes.c_int]),
@@ -211,7 +212,13 @@ class Game:
         return list(buf)
 
     def score(self):
+        """Black minus white minus komi as the reference computes it (go.py:202-218): Tromp-Taylor area,
+        except that stones bordering a neutral empty region are not counted (reference quirk)."""
         return float(golib().bk_pos_score(ctypes.byref(self._pos), ctypes.c_float(self.komi)))
+
+    def area_score(self):
+        """Tromp-Taylor area score proper."""
+        return float(golib().bk_pos_area_score(ctypes.byref(self._pos), ctypes.c_float(self.komi)))
 
     def features_u8(self, fresh=False):
         out = np.empty((27, 9, 9), np.uint8)

@@ -401,8 +401,13 @@ class MCTS:
         node = self._table.get(node.key(), node)
         if node._terminal:
             return node
-        if node._kids is None:
-            return node.find_random_child()
+        if not node._kids:
+            # not expanded, or no legal move at all (the reference's max() over an empty set raises
+            # here): sample from the policy, passing as the last resort
+            child = node.find_random_child()
+            if node is self.root and node._kids is not None:
+                self.set_root(child)
+            return child
         best, best_n = None, None
         for c in node._kids:
             s = float("-inf") if c.N == 0 else c.N

@@ -274,17 +274,105 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     t0 = time.perf_counter()
     steps = run_pools(pools, evaluator, progress)
     dt = time.perf_counter() - t0
-    games = {}
+    games, visits = {}, {}
     for part, pool in zip(parts, pools):
         for i, g in enumerate(part):
             games[g] = {"moves": pool.moves(i), "score": pool.info(i)["score"]}
+            if record_visits:
+                visits[g] = [pool.visits(i, ply) for ply in range(len(games[g]["moves"]))]
     local = pool_stats(pools) if pools else np.zeros(STATS_LEN)
     total, t_reduce = all_reduce_stats(local, reduce_device)
     for p in pools:
         p.close()
     named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}
     named["first_move_hist"] = total[len(STATS_FIELDS):].astype(int).tolist()
-    return ({"games": games, "seconds": dt, "steps": steps, "local_stats": local, "allreduce_s": t_reduce}, named)
+    return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local,
+             "allreduce_s": t_reduce}, named)
+
+
+# ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------
+POLICY_MAX_TURNS = 70  # selfplay.py:16
+
+
+def legal_sample(pi, game, device=None):
+    """Sample a move from the policy; if it is illegal walk the policy's moves in descending
+    probability and take the first legal one; None if there is none (selfplay.py:35-47)."""
+    import torch
+    from . import nnet
+    device = device or torch.device("cpu")
+    move = nnet.policy_sample(pi, game, device)
+    k, moves = 0, None
+    while not game.is_legal(move.item()):
+        if k == 0:
+            moves = torch.topk(nnet.policy_dist(pi, game, device).probs, k=81).indices
+        elif k > 80:
+            return None
+        move = moves[k]
+        k += 1
+    return move
+
+
+def playout(game, pi_1, pi_2, device=None):
+    """pi_1 (to move first) against pi_2 until turn > 70 or a side has no legal sample (selfplay.py:18-33)."""
+    while True:
+        for pi in (pi_1, pi_2):
+            if game.turn > POLICY_MAX_TURNS:
+                return
+            mv = legal_sample(pi, game, device)
+            if mv is None:
+                return
+            game.play_move(mv.item())
+
+
+def policy_self_play(pi1, pi2, num_games, device=None):
+    """The reference's self_play(pi1, pi2, num_games) (selfplay.py:49-57); games are scored by area
+    (+1 black / -1 white) instead of by a gnugo subprocess."""
+    games, results = [], []
+    for _ in range(num_games):
+        g = go.Game(moves=[])
+        playout(g, pi1, pi2, device)
+        games.append(g.moves)
+        results.append(1 if g.area_score() > 0 else -1)
+    return games, results
+
+
+def batched_policy_playouts(probs_fn, n_games, seed_base=0, max_turns=POLICY_MAX_TURNS):
+    """The same playouts for many games in lock-step: one policy batch per ply instead of one
+    forward per move per game.  probs_fn(uint8 feats [B,27,9,9]) -> probs [B,81].  Each game samples
+    with its own numpy Generator (seed_base + gid); an illegal sample falls back to the policy's
+    descending order, as legal_sample does."""
+    games = [go.Game(moves=[]) for _ in range(n_games)]
+    rngs = [np.random.default_rng(seed_base + i) for i in range(n_games)]
+    live = list(range(n_games))
+    while live:
+        feats = np.stack([games[i].features_u8() for i in live])
+        probs = np.asarray(probs_fn(feats), dtype=np.float64)
+        nxt = []
+        for row, i in enumerate(live):
+            g, p = games[i], probs[row] / probs[row].sum()
+            mv = int(rngs[i].choice(81, p=p))
+            if not g.is_legal(mv):
+                mv = next((int(m) for m in np.argsort(-p, kind="stable") if g.is_legal(int(m))), None)
+            if mv is None:
+                continue
+            g.play_move(mv)
+            if g.turn <= max_turns:
+                nxt.append(i)
+        live = nxt
+    return [g.moves for g in games], [1 if g.area_score() > 0 else -1 for g in games]
+
+
+def write_records(out_dir, games, visits=None, komi=5.5):
+    """Self-play records: one SGF per game (reference dialect, go.py:528-564) + games.json with the
+    move lists, scores and (when recorded) the per-ply root visit counts."""
+    os.makedirs(out_dir, exist_ok=True)
+    for gid, g in sorted(games.items()):
+        s = g["score"]
+        go.write_sgf(g["moves"], os.path.join(out_dir, f"game_{gid:05d}.sgf"), komi=komi, B="boke-amd", W="boke-amd",
+                     result=("B+" if s > 0 else "W+") + f"{abs(s)}")
+    rec = {str(k): dict(v, visits=(visits or {}).get(k)) for k, v in games.items()}
+    with open(os.path.join(out_dir, "games.json"), "w") as f:
+        json.dump(rec, f)
 
 
 def main():
@@ -296,7 +384,7 @@ def main():
     ap.add_argument("--value", default=None)
     ap.add_argument("--max-batch", type=int, default=8192)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--out", default=None, help="write this rank's games as JSON")
+    ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     args = ap.parse_args()
 
     import torch
@@ -323,7 +411,7 @@ def main():
     ev = EngineEvaluator(eng)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads,
-                             reduce_device=torch.device("cuda", local_rank))
+                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)))
     secs = local["seconds"]
     if world > 1:
         t = torch.tensor([secs], dtype=torch.float64, device="cuda")
@@ -336,8 +424,7 @@ def main():
                           "black_wins": total["black_wins"], "white_wins": total["white_wins"],
                           "allreduce_ms": local["allreduce_s"] * 1e3, "mean_batch": ev.positions / max(1, ev.batches)}))
     if args.out:
-        with open(f"{args.out}.rank{rank}.json", "w") as f:
-            json.dump({str(k): v for k, v in local["games"].items()}, f)
+        write_records(os.path.join(args.out, f"rank{rank}"), local["games"], local["visits"])
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -66,8 +66,11 @@ int bk_pos_is_legal(const bk_pos *p, int move);
 int bk_pos_legal_moves(const bk_pos *p, uint8_t legal[81]);
 /* Game.get_liberties go.py:220-243 (refreshes the cache exactly as the reference does) */
 void bk_pos_liberties(bk_pos *p, uint8_t out[81]);
-/* Game.score go.py:202-218 (Tromp-Taylor area, black minus white minus komi) */
+/* Game.score go.py:202-218, bug-compatible: the reference also repaints the stones bordering each
+ * empty region, so stones next to neutral points are not counted (pinned by the GTP transcript) */
 float bk_pos_score(const bk_pos *p, float komi);
+/* Tromp-Taylor area score proper: black stones+territory minus white's minus komi (self-play results) */
+float bk_pos_area_score(const bk_pos *p, float komi);
 /* single-point eye test used by the build's playout generator: all on-board neighbours are `color` */
 int bk_pos_eye_like(const bk_pos *p, int sq, int color);
 

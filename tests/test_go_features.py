@@ -121,7 +121,8 @@ def test_score_area():
     g = go.Game()
     for m in [36, 44, 37, 43, 38, 42, 39, 41]:    # incomplete walls: regions touch both colours -> neutral
         g.play_move(m)
-    assert g.score() == 4 - (4 + 5.5)
+    assert g.area_score() == 4 - (4 + 5.5)
+    assert g.score() == 0 - (0 + 5.5)             # reference quirk: stones bordering neutral points vanish
     b = "X" * 36 + "." * 9 + "O" * 36
     assert go.Game(board=b).score() == 36 - (36 + 5.5)
     b = "X" * 36 + "." * 45

@@ -155,3 +155,36 @@ def test_pool_respects_cap_and_counts():
     npol = sum(pool.info(g)["n_policy_evals"] for g in range(10))
     # every evaluated position is a new value, except policy requests for nodes whose value was known
     assert nv <= ev.positions <= nv + npol
+
+
+def test_policy_playouts_reference_surface_and_records(tmp_path):
+    """legal_sample / playout / self_play of bin/selfplay.py:18-57 on our nets, the batched variant, and
+    the self-play record writer."""
+    f = FakeNets()
+    pi = _Wrap(f.policy)
+    torch.manual_seed(1)
+    g = go.Game(moves=[])
+    mv = selfplay.legal_sample(pi, g)
+    assert 0 <= mv.item() < 81 and g.is_legal(mv.item())
+    games, results = selfplay.policy_self_play(pi, pi, 2)
+    assert len(games) == 2 and all(len(m) == 71 for m in games) and set(results) <= {1, -1}
+
+    def probs_fn(x):
+        return torch.softmax(torch.from_numpy(f.policy(x)), dim=1).numpy()
+    a = selfplay.batched_policy_playouts(probs_fn, 6, seed_base=3)
+    b = selfplay.batched_policy_playouts(probs_fn, 6, seed_base=3)
+    assert a == b and all(len(m) == 71 for m in a[0]) and len({tuple(m) for m in a[0]}) == 6
+    for moves in a[0]:                                     # every recorded move was legal when played
+        r = go.Game()
+        for m in moves:
+            r.play_move(m)
+
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    local, _ = selfplay.self_play(ev, n_games=3, rollouts=20, expand_thresh=4, max_turns=5, cap=400, threads=1,
+                                  record_visits=1)
+    selfplay.write_records(str(tmp_path), local["games"], local["visits"])
+    import json
+    rec = json.load(open(tmp_path / "games.json"))
+    assert set(rec) == {"0", "1", "2"} and len(rec["0"]["visits"]) == len(rec["0"]["moves"]) == 6
+    assert sum(rec["0"]["visits"][0].values()) == 20
+    assert go.get_moves(str(tmp_path / "game_00000.sgf")) == rec["0"]["moves"]

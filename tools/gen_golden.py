@@ -158,13 +158,42 @@ def layer_acts(net, x):
     return np.stack(acts), h.reshape(-1).numpy().copy()
 
 
+GTP_SESSION = [
+    "protocol_version", "name", "version", "1 known_command genmove", "known_command frobnicate",
+    "list_commands", "boardsize 9", "boardsize 19", "komi 6.5", "komi abc", "komi", "clear_board",
+    "play b e5", "play w e5", "play b zz", "play", "genmove w", "showboard", "last_move", "move_history",
+    "undo", "undo", "final_score", "play w c3", "play w g7", "last_move", "move_history", "final_score",
+    "genmove b", "7 genmove b", "reg_genmove w", "move_history", "set_fixed_handicap 2", "clear_board",
+    "set_fixed_handicap 9", "set_fixed_handicap 3", "showboard", "final_score", "genmove w", "last_move",
+    "frobnicate now", "pondering maybe", "pondering off", "quit",
+]
+
+
+def gtp_transcript(pi, v):
+    """Drive the reference's GTP.send() with a scripted session (200 rollouts per genmove)."""
+    import bokego.gtp as rgtp
+    mcts.MCTS._val_cache.clear(); mcts.MCTS._dist_cache.clear(); mcts.MCTS._fts_cache.clear()
+    torch.manual_seed(0)
+    g = rgtp.GTP(mcts.Go_MCTS(), pi, v, no_sim=True, time_lim=None, n_rollouts=200, pondering=False)
+    g.running = True
+    out = []
+    for cmd in GTP_SESSION:
+        out.append([cmd, g.send(cmd)])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-gtp", action="store_true")
     ap.add_argument("--skip-mcts", action="store_true")
     ap.add_argument("--playouts", type=int, default=256)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     pi, v = build_nets()
+    if args.only_gtp:
+        with open(os.path.join(OUT, "gtp_transcript.json"), "w") as f:
+            json.dump({"n_rollouts": 200, "session": gtp_transcript(pi, v)}, f, indent=0)
+        return
 
     # ---- weights --------------------------------------------------------------------
     save_bkw(os.path.join(OUT, "policy_19.bkw"), state_dict_to_tensors(pi.state_dict()))
@@ -257,6 +286,8 @@ def main():
                   f"{time.time() - t0:.1f}s", traces[name]["n_value_evals"], traces[name]["n_policy_evals"])
         with open(os.path.join(OUT, "mcts_trace.json"), "w") as f:
             json.dump(traces, f)
+    with open(os.path.join(OUT, "gtp_transcript.json"), "w") as f:
+        json.dump({"n_rollouts": 200, "session": gtp_transcript(pi, v)}, f, indent=0)
 
 
 if __name__ == "__main__":
