@@ -237,7 +237,9 @@ class GTP(MCTS):
         elif self.n_rollouts:
             self.rollout(self.n_rollouts)
         self._last_root = self.root
-        mv = self.choose().last_move
+        # a terminal root (last move was a pass, or turn > MAX_TURNS) has nothing to choose from: the
+        # reference returns the root's own last move there, which is PASS only in the first case
+        mv = go.PASS if self.root._terminal else self.choose().last_move
         self.genmove_seconds.append(default_timer() - t0)
         self._move_history.append(mv)
         self._undid = False

@@ -99,3 +99,16 @@ def test_config3_genmove_1600_rollouts_matches_reference(sds):
     print(f"\nconfig3: {dt*1e3:.0f} ms/move, {ev.n_positions/len(t['moves']):.0f} evals/move, "
           f"mean batch {ev.n_positions/ev.n_batches:.1f}, reference evals: {t['n_value_evals']} value / {t['n_policy_evals']} policy")
     assert ev.n_positions / ev.n_batches > 20
+
+
+def test_gtp_session_matches_reference_transcript_on_gpu(sds):
+    """The scripted GTP session recorded from the reference (200 rollouts per genmove), on the HIP nets."""
+    from bokego_amd import nnet
+    from bokego_amd.gtp import GTP
+    from bokego_amd.mcts import Go_MCTS
+    t = json.load(open(os.path.join(GOLDEN, "gtp_transcript.json")))
+    g = GTP(Go_MCTS(), nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1]), no_sim=True, time_lim=None,
+            n_rollouts=t["n_rollouts"])
+    g.running = True
+    for cmd, want in t["session"]:
+        assert g.send(cmd) == want, cmd
