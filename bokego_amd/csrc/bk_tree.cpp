@@ -32,7 +32,7 @@ struct TNode {
     int mv = BK_NO_MOVE;
 };
 
-enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_WAIT_LEAF, S_CHOOSE, S_DONE };
+enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_WAIT_LEAF, S_CHOOSE, S_DONE, S_IDLE };
 
 struct Rng {  // xoshiro256** seeded by splitmix64: per-game stream, independent of how games are sharded
     uint64_t s[4];
@@ -86,6 +86,7 @@ struct Game {
     std::vector<std::vector<std::pair<int16_t, int32_t>>> visit_log;  // per ply: (move, N) of the root's children
     uint64_t n_value_evals = 0, n_policy_evals = 0, n_requests = 0;
     float final_score = 0.f;
+    bool manual = false;  // driven from outside: rollouts are added, moves chosen/played by the caller
 
     Game(const bk_search_params& p, uint64_t seed) : prm(p), rng(seed) {}
 
@@ -223,14 +224,22 @@ struct Game {
 
     bool has_request() const { return !req_policy.empty() || !req_value.empty(); }
 
+    void reroot(int id) {  // MCTS.set_root (mcts.py:153-157): keep the subtree, expand the new root
+        root = id;
+        if (prm.prune) prune();
+        state = S_ROOT_EXPAND;
+    }
+
     // run until network outputs are needed (returns true) or the game is over (false)
     bool advance() {
         for (;;) {
             switch (state) {
                 case S_INIT: {
-                    bk_pos p;
-                    bk_pos_init(&p);
-                    root = intern(p);
+                    if (root < 0) {
+                        bk_pos p;
+                        bk_pos_init(&p);
+                        root = intern(p);
+                    }
                     state = S_ROOT_EXPAND;
                     break;
                 }
@@ -245,6 +254,10 @@ struct Game {
                     break;
                 case S_ROOT_READY:
                     add_noise(root);
+                    if (manual) {
+                        state = remaining > 0 ? S_SEARCH : S_IDLE;
+                        break;
+                    }
                     if (nodes[root].terminal || nodes[root].n_kids == 0) {
                         final_score = bk_pos_area_score(&nodes[root].pos, prm.komi);
                         state = S_DONE;
@@ -275,7 +288,7 @@ struct Game {
                         --remaining;
                     }
                     if (waiting) { state = S_WAIT_LEAF; return true; }
-                    state = S_CHOOSE;
+                    state = manual ? S_IDLE : S_CHOOSE;
                     break;
                 }
                 case S_WAIT_LEAF:
@@ -299,6 +312,9 @@ struct Game {
                     state = S_ROOT_EXPAND;
                     break;
                 }
+                case S_IDLE:
+                    if (remaining > 0) { state = S_SEARCH; break; }
+                    return false;
                 case S_DONE:
                     return false;
             }
@@ -454,6 +470,56 @@ int bk_pool_game_visits(const bk_pool* p, int g, int ply, int16_t* moves, int32_
         N[i] = log[ply][i].second;
     }
     return (int)log[ply].size();
+}
+
+/* ---- manual control: the single-tree MCTS surface (rollout / choose / set_root) on a pool game ---- */
+void bk_pool_set_manual(bk_pool* p, int on) {
+    for (auto& g : p->games) g.manual = on != 0;
+}
+
+int bk_pool_add_rollouts(bk_pool* p, int g, int n) {
+    if (g < 0 || g >= (int)p->games.size() || n < 0) return -1;
+    p->games[g].remaining += n;
+    return p->games[g].remaining;
+}
+
+int bk_pool_choose(bk_pool* p, int g) {  // MCTS.choose at the root (mcts.py:110-131); returns the move, BK_NO_MOVE if none
+    if (g < 0 || g >= (int)p->games.size()) return BK_NO_MOVE;
+    Game& gm = p->games[g];
+    if (gm.root < 0 || gm.has_request() || gm.nodes[gm.root].terminal || gm.nodes[gm.root].n_kids == 0) return BK_NO_MOVE;
+    const int best = gm.pick_move();
+    gm.moves.push_back((int16_t)gm.nodes[best].mv);
+    const int mv = gm.nodes[best].mv;
+    gm.reroot(best);
+    return mv;
+}
+
+int bk_pool_play(bk_pool* p, int g, int move) {  // make `move` (or BK_PASS) the new root; 0 or a BK_ILLEGAL_* code
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    Game& gm = p->games[g];
+    if (gm.has_request()) return -1;
+    if (gm.root < 0) { bk_pos q; bk_pos_init(&q); gm.root = gm.intern(q); }
+    bk_pos q = gm.nodes[gm.root].pos;
+    const int rc = bk_pos_play(&q, move);
+    if (rc) return rc;
+    gm.moves.push_back((int16_t)move);
+    gm.reroot(gm.intern(q));
+    return 0;
+}
+
+int bk_pool_set_position(bk_pool* p, int g, const bk_pos* pos) {  // new root from an arbitrary position (clear_board, handicap)
+    if (g < 0 || g >= (int)p->games.size() || !pos) return -1;
+    Game& gm = p->games[g];
+    if (gm.has_request()) return -1;
+    gm.moves.clear();
+    gm.reroot(gm.intern(*pos));
+    return 0;
+}
+
+int bk_pool_root_pos(const bk_pool* p, int g, bk_pos* out) {
+    if (g < 0 || g >= (int)p->games.size() || p->games[g].root < 0) return -1;
+    *out = p->games[g].nodes[p->games[g].root].pos;
+    return 0;
 }
 
 int bk_pool_root_children(const bk_pool* p, int g, int16_t* moves, int32_t* N, double* V) {

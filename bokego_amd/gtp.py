@@ -21,8 +21,11 @@ from .mcts import MCTS, Go_MCTS
 FLOWERS9 = (20, 60, 24, 56, 40)
 
 
-class GTP(MCTS):
-    """MCTS + Go Text Protocol.  kwargs as the reference: pondering, time_lim (20.0), n_rollouts."""
+class _GTPProtocol:
+    """Go Text Protocol on a tree searcher (mixed in before MCTS or NativeMCTS).
+    kwargs as the reference: pondering, time_lim (20.0), n_rollouts."""
+
+    _node = Go_MCTS   # node type of fresh roots
 
     colors = ("black", "b", "w", "white")
     commands = ("name", "boardsize", "clear_board", "komi", "play", "genmove", "reg_genmove", "final_score",
@@ -75,7 +78,7 @@ class GTP(MCTS):
         this_turn = self.root.turn
         c = cmd[0]
 
-        if c not in GTP.commands:
+        if c not in _GTPProtocol.commands:
             out = f"unknown command '{c}'"
         elif c == "protocol_version":
             out, valid = "2", True
@@ -85,14 +88,14 @@ class GTP(MCTS):
             out, valid = "boke", True
         elif c == "known_command":
             if len(cmd) == 2:
-                out, valid = ("true" if cmd[1] in GTP.commands else "false"), True
+                out, valid = ("true" if cmd[1] in _GTPProtocol.commands else "false"), True
         elif c == "boardsize":
             if len(cmd) != 2 or cmd[1] != "9":
                 out = "boke only plays on 9x9 board"
             else:
                 valid = True
         elif c == "clear_board":
-            self.set_root(Go_MCTS())
+            self.set_root(self._node())
             valid = True
         elif c == "komi":
             if len(cmd) < 2:
@@ -104,7 +107,7 @@ class GTP(MCTS):
                 except ValueError:
                     out = "invalid komi value"
         elif c == "play":
-            if len(cmd) < 3 or cmd[1] not in GTP.colors:
+            if len(cmd) < 3 or cmd[1] not in _GTPProtocol.colors:
                 out = "usage: play <color> <vertex>"
             elif cmd[2] == "resign":
                 valid, self.running = True, False
@@ -134,7 +137,7 @@ class GTP(MCTS):
         elif c == "showboard":
             out, valid = "\n" + str(self.root), True
         elif c in ("genmove", "reg_genmove"):
-            if len(cmd) != 2 or cmd[1] not in GTP.colors:
+            if len(cmd) != 2 or cmd[1] not in _GTPProtocol.colors:
                 out = f"usage: {c} <color>"
             else:
                 turn = 0 if "b" in cmd[1] else 1
@@ -163,7 +166,7 @@ class GTP(MCTS):
         elif c == "quit":
             self.running, valid = False, True
         elif c in ("help", "list_commands"):
-            out, valid = "\n".join(GTP.commands), True
+            out, valid = "\n".join(_GTPProtocol.commands), True
         elif c == "clear_cache":
             self.clear_cache()
             self._undid, valid = True, True
@@ -183,7 +186,7 @@ class GTP(MCTS):
             else:
                 stones = FLOWERS9[:int(cmd[1])]
                 board = "".join(go.BLACK if i in stones else go.EMPTY for i in range(81))
-                self.set_root(Go_MCTS(board=board, turn=1))
+                self.set_root(self._node(board=board, turn=1))
                 out, valid = " ".join(go.unsquash(list(stones))), True
         elif c == "printsgf":
             path = cmd[1] if len(cmd) == 2 else os.path.join(os.getcwd(), "bokego.sgf")
@@ -201,10 +204,12 @@ class GTP(MCTS):
                 except go.IllegalMove:
                     out = "illegal move in sgf"
         elif c == "analyze":
-            if len(cmd) != 3 or cmd[1] not in GTP.colors or not cmd[2].isnumeric():
+            if len(cmd) != 3 or cmd[1] not in _GTPProtocol.colors or not cmd[2].isnumeric():
                 out = "usage: analyze <color> <interval>"
             elif (0 if "b" in cmd[1] else 1) != this_turn % 2:
                 out = f"it is not {cmd[1]}'s turn"
+            elif not hasattr(self, "N"):
+                out = "analyze needs the Python tree (start without --native)"
             else:
                 return self.analyze(int(cmd[2]))
         elif c == "pondering":
@@ -266,6 +271,18 @@ class GTP(MCTS):
             yield out + "\n"
 
 
+class GTP(_GTPProtocol, MCTS):
+    """The reference's GTP(MCTS) (gtp.py:16) on the batched Python tree."""
+
+
+from .mcts_native import NativeMCTS, Position  # noqa: E402
+
+
+class NativeGTP(_GTPProtocol, NativeMCTS):
+    """Same protocol on the native tree core: ~10x less host time per genmove."""
+    _node = Position
+
+
 def load_state_dict(path):
     """A reference checkpoint ({"model_state_dict": ...}, boke.py:31-37), a bare state_dict, or a BKW1 file."""
     if path.endswith(".bkw"):
@@ -286,12 +303,13 @@ def main(argv=None):
     ap.add_argument("-g", "--gpu", type=int, default=0, help="GPU index")
     ap.add_argument("--precision", choices=["f16x2", "f32"], default=None)
     ap.add_argument("--ponder", action="store_true")
+    ap.add_argument("--python-tree", action="store_true", help="search with the Python tree (needed for `analyze`)")
     args = ap.parse_args(argv)
 
     from . import nnet
     pi, val = nnet.HipPolicyNet(load_state_dict(args.p), device_id=args.gpu), nnet.HipValueNet(load_state_dict(args.v), device_id=args.gpu)
-    gtp = GTP(Go_MCTS(), pi, val, no_sim=True, time_lim=None if args.r else args.t, n_rollouts=args.r,
-              pondering=args.ponder)
+    cls, root = (GTP, Go_MCTS()) if args.python_tree else (NativeGTP, Position())
+    gtp = cls(root, pi, val, no_sim=True, time_lim=None if args.r else args.t, n_rollouts=args.r, pondering=args.ponder)
     if args.precision:
         gtp.evaluator.engine.set_precision(args.precision)
     gtp.start()

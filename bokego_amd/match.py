@@ -167,10 +167,11 @@ def main(argv=None):
     ap.add_argument("--sgf", default=None, help="prefix for SGF records")
     args = ap.parse_args(argv)
     from . import nnet
-    from .gtp import GTP, load_state_dict
-    from .mcts import Go_MCTS
+    from .gtp import NativeGTP, load_state_dict
+    from .mcts_native import Position
     pi, val = nnet.HipPolicyNet(load_state_dict(args.p)), nnet.HipValueNet(load_state_dict(args.v))
-    a = InProcessEngine(GTP(Go_MCTS(), pi, val, no_sim=True, time_lim=None, n_rollouts=args.r), name=f"boke-hip-r{args.r}")
+    a = InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=args.r),
+                        name=f"boke-hip-r{args.r}")
     if args.opponent == "policy":
         b = PolicyEngine(pi)
     else:

@@ -52,6 +52,12 @@ TREE_SYMBOLS = {
     "bk_pool_game_moves": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int]),
     "bk_pool_root_children": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, _VP]),
     "bk_pool_game_visits": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
+    "bk_pool_set_manual": (None, [_VP, ctypes.c_int]),
+    "bk_pool_add_rollouts": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int]),
+    "bk_pool_choose": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "bk_pool_play": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int]),
+    "bk_pool_set_position": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
+    "bk_pool_root_pos": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
 }
 _tree_ready = False
 

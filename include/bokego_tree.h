@@ -19,6 +19,8 @@
 
 #include <stdint.h>
 
+#include "bokego_go.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -70,6 +72,20 @@ int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);
 int bk_pool_game_moves(const bk_pool *p, int g, int16_t *out, int cap);
 /* visit counts of the root's children when ply `ply` was chosen (needs record_visits); returns their number */
 int bk_pool_game_visits(const bk_pool *p, int g, int ply, int16_t *moves, int32_t *N);
+/*
+ * Manual control: the reference's single-tree surface on a pool game.  With manual mode on, a game
+ * only searches while it has rollouts outstanding and never moves by itself:
+ *   bk_pool_add_rollouts  = MCTS.rollout(n)        (mcts.py:133-151; drive collect/deliver until B == 0)
+ *   bk_pool_choose        = MCTS.choose()          (mcts.py:110-131; re-roots, returns the move)
+ *   bk_pool_play          = set_root(root.make_move(mv))  (gtp.py:332-337: an outside move)
+ *   bk_pool_set_position  = set_root(Go_MCTS(board=...))  (clear_board, handicap)
+ */
+void bk_pool_set_manual(bk_pool *p, int on);
+int bk_pool_add_rollouts(bk_pool *p, int g, int n);
+int bk_pool_choose(bk_pool *p, int g);
+int bk_pool_play(bk_pool *p, int g, int move);
+int bk_pool_set_position(bk_pool *p, int g, const bk_pos *pos);
+int bk_pool_root_pos(const bk_pool *p, int g, bk_pos *out);
 /* root children of game g in ascending move order; returns their number */
 int bk_pool_root_children(const bk_pool *p, int g, int16_t *moves, int32_t *N, double *V);
 

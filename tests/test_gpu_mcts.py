@@ -112,3 +112,21 @@ def test_gtp_session_matches_reference_transcript_on_gpu(sds):
     g.running = True
     for cmd, want in t["session"]:
         assert g.send(cmd) == want, cmd
+
+
+def test_config3_on_native_tree(sds):
+    """Same BASELINE config 3 trace (1600 rollouts x 10 moves) with the tree in C++ (NativeMCTS)."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))["r1600"]
+    tree = NativeMCTS(Position(), nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1]))
+    t0 = time.time()
+    for ref in t["moves"]:
+        tree.rollout(t["rollouts"])
+        kids = {m: n for m, (n, _) in tree.child_stats().items()}
+        assert kids == {int(k): v for k, v in ref["child_N"].items()}
+        assert abs(tree.winrate() - ref["root_winrate"]) < 1e-4
+        assert tree.choose().last_move == ref["move"]
+    dt = (time.time() - t0) / len(t["moves"])
+    ev = tree.evaluator
+    print(f"\nconfig3 native: {dt*1e3:.1f} ms/move, mean batch {ev.positions/ev.batches:.1f}")
