@@ -286,13 +286,13 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
         const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
         for (int e = tid; e < nb * 2187; e += 256) {
             const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            act[in_addr(pos5(b, y, x), c)] = X[e];
+            act[in_addr(pos5(b, y, x), c)] = __builtin_nontemporal_load(X + e);  // streamed once: keep L2 for the weights
         }
     } else {
         const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
         for (int e = tid; e < nb * 2187; e += 256) {
             const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            act[in_addr(pos5(b, y, x), c)] = (float)X[e];
+            act[in_addr(pos5(b, y, x), c)] = (float)__builtin_nontemporal_load(X + e);
         }
     }
     __syncthreads();

@@ -276,11 +276,11 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
         if (a.feats_dtype == BK_FEATS_F32_) {
             const float* src = static_cast<const float*>(a.feats) + (size_t)(b0 + b) * 2187 + q;
 #pragma unroll
-            for (int c = 0; c < 27; ++c) v[c] = src[c * 81];
+            for (int c = 0; c < 27; ++c) v[c] = __builtin_nontemporal_load(src + c * 81);  // streamed once: keep L2 for the weights
         } else {
             const uint8_t* src = static_cast<const uint8_t*>(a.feats) + (size_t)(b0 + b) * 2187 + q;
 #pragma unroll
-            for (int c = 0; c < 27; ++c) v[c] = (float)src[c * 81];
+            for (int c = 0; c < 27; ++c) v[c] = (float)__builtin_nontemporal_load(src + c * 81);
         }
 #pragma unroll
         for (int c = 27; c < 32; ++c) v[c] = 0.f;
