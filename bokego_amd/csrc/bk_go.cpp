@@ -155,10 +155,71 @@ uint64_t full_hash(const bk_pos* p) {
 
 inline uint8_t sep(int v) { return (uint8_t)(v > 6 ? 7 : v); }  // `separate`, nnet.py:253-258
 
+typedef unsigned __int128 u128;
+inline u128 bit(int s) { return (u128)1 << s; }
+inline int popcnt(u128 m) { return __builtin_popcountll((uint64_t)m) + __builtin_popcountll((uint64_t)(m >> 64)); }
+
+struct NbrMasks {
+    u128 m[NN];
+    NbrMasks() {
+        for (int s = 0; s < NN; ++s) {
+            m[s] = 0;
+            for (int k = 0; k < T.nn[s]; ++k) m[s] |= bit(T.nbr[s][k]);
+        }
+    }
+};
+const NbrMasks NBR;
+
+// chains of a position as bit masks: stones, all neighbouring points, liberties
+struct Groups {
+    int8_t gid[NN];
+    u128 stones[NN], nbrs[NN], libs[NN];
+    int size[NN];
+    u128 empty;
+    explicit Groups(const int8_t* b) {
+        empty = 0;
+        for (int s = 0; s < NN; ++s) {
+            gid[s] = -1;
+            if (b[s] == BK_EMPTY) empty |= bit(s);
+        }
+        int ng = 0;
+        int8_t stack[NN];
+        for (int s = 0; s < NN; ++s) {
+            if (b[s] == BK_EMPTY || gid[s] >= 0) continue;
+            const int g = ng++;
+            u128 st = 0, nb = 0;
+            int sp = 0, n = 0;
+            stack[sp++] = (int8_t)s;
+            gid[s] = (int8_t)g;
+            while (sp) {
+                const int q = stack[--sp];
+                st |= bit(q);
+                nb |= NBR.m[q];
+                ++n;
+                for (int k = 0; k < T.nn[q]; ++k) {
+                    const int t = T.nbr[q][k];
+                    if (b[t] == b[s] && gid[t] < 0) { gid[t] = (int8_t)g; stack[sp++] = (int8_t)t; }
+                }
+            }
+            stones[g] = st;
+            nbrs[g] = nb;
+            libs[g] = nb & empty;
+            size[g] = n;
+        }
+    }
+};
+
+// nnet.features() (nnet.py:182-262).  Per candidate move the reference places the stone, removes
+// captured chains and flood-fills the new chain (nnet.py:241-247); here every chain's stone /
+// neighbour / liberty set is computed once as a 128-bit mask and a move is a few mask operations:
+//   captured   = opponent neighbour chains whose only liberty is the move
+//   new chain  = move + own neighbour chains
+//   liberties  = (empty neighbours of the new chain, minus the move) + captured points touching it
 template <typename O>
 void features_impl(bk_pos* p, O* out, int fresh) {
     for (int i = 0; i < 27 * NN; ++i) out[i] = 0;
     const int8_t me = (p->turn & 1) ? BK_WHITE : BK_BLACK;
+    const int8_t opp = me == BK_WHITE ? BK_BLACK : BK_WHITE;
     uint8_t libs_fresh[NN];
     const uint8_t* libs;
     if (fresh) {
@@ -178,17 +239,28 @@ void features_impl(bk_pos* p, O* out, int fresh) {
         if (lv) out[(6 + (lv > 6 ? 6 : lv - 1)) * NN + s] = sep(lv);
     }
     if (p->last_move >= 0) out[4 * NN + p->last_move] = 1;
-    MoveResult r;
-    Chain ch;
+    const Groups G(p->board);
     for (int s = 0; s < NN; ++s) {
         if (p->board[s] != BK_EMPTY || s == p->ko) continue;
-        if (try_move(p, s, r) != 0) continue;
+        const u128 me_bit = bit(s);
+        u128 chain_nbrs = NBR.m[s], lib = NBR.m[s] & G.empty, captured = 0;
+        int cap_dup = 0;  // the reference counts a captured chain once per point at which it touches the move
+        for (int k = 0; k < T.nn[s]; ++k) {
+            const int t = T.nbr[s][k];
+            const int g = G.gid[t];
+            if (p->board[t] == opp) {
+                if (G.libs[g] == me_bit) { captured |= G.stones[g]; cap_dup += G.size[g]; }
+            } else if (p->board[t] == me) {
+                chain_nbrs |= G.nbrs[g];
+                lib |= G.libs[g];
+            }
+        }
+        lib = (lib & ~me_bit) | (captured & chain_nbrs);
+        const int la = popcnt(lib);
+        if (la == 0) continue;  // suicide
         out[5 * NN + s] = 1;
-        chain_at(r.board, s, ch);
-        const int la = ch.nlibs;  // >= 1 for a legal move
         out[(13 + (la > 6 ? 6 : la - 1)) * NN + s] = sep(la);
-        const int cp = r.n_captured_dup;
-        if (cp) out[(20 + (cp > 6 ? 6 : cp - 1)) * NN + s] = sep(cp);
+        if (cap_dup) out[(20 + (cap_dup > 6 ? 6 : cap_dup - 1)) * NN + s] = sep(cap_dup);
     }
 }
 

@@ -390,6 +390,7 @@ def main():
     ap.add_argument("--value", default=None)
     ap.add_argument("--max-batch", type=int, default=8192)
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--pools", type=int, default=2, help="lock-step pools per rank (host/GPU overlap)")
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     args = ap.parse_args()
 
@@ -416,7 +417,7 @@ def main():
                      max_batch=args.max_batch)
     ev = EngineEvaluator(eng)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
-                             max_turns=args.max_turns, cap=args.max_batch, threads=args.threads,
+                             max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
                              reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)))
     secs = local["seconds"]
     if world > 1:
