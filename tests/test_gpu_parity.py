@@ -169,3 +169,37 @@ def test_f16x2_overflow_falls_back_to_fp32(weights, oracle):
     fast.eval((x / 4000.0).astype(np.float32), logits=True, probs=False, value=True)
     assert fast.stats()["f16_overflow_fallbacks"] == 1
     fast.close(); exact.close()
+
+
+def test_abi_edge_cases(weights, gold):
+    """Empty batch, max batch, argument errors through the raw C ABI."""
+    import ctypes
+    from bokego_amd import _lib
+    from bokego_amd.engine import LeafEngine
+    f, n = gold
+    e = LeafEngine(weights[0], weights[1], max_batch=7)
+    lib, h = e._lib, e._h
+    empty = np.zeros((0, 27, 9, 9), np.float32)
+    o = e.eval(empty, logits=True, probs=True, value=True)             # B = 0 is a no-op
+    assert o["logits"].shape == (0, 81) and o["value"].shape == (0,)
+    x = f[:7].astype(np.float32)
+    o = e.eval(x, logits=True, probs=True, value=True)                 # B == max_batch
+    assert np.abs(o["logits"] - n["logits_b1"][:7]).max() < TOL_LOGIT
+    fp = ctypes.c_void_p
+    out = np.empty((7, 81), np.float32)
+    assert lib.bk_eval(h, x.ctypes.data, 7, 0, None, None, None) == -1                 # empty want mask
+    assert lib.bk_eval(h, x.ctypes.data, 7, _lib.BK_WANT_PROBS, None, None, None) == -1  # missing output buffer
+    assert lib.bk_eval(h, None, 7, _lib.BK_WANT_PROBS, None, out.ctypes.data, None) == -1  # missing input
+    assert lib.bk_eval(h, x.ctypes.data, 8, _lib.BK_WANT_PROBS, None, out.ctypes.data, None) == -4  # BK_ERR_BATCH
+    assert b"max_batch" in lib.bk_last_error(h)
+    assert lib.bk_wait(h, 12345) == -1                                                  # unknown ticket
+    assert lib.bk_engine_set_precision(h, 7) == -1
+    # more tickets than BK_MAX_INFLIGHT
+    tickets = [e.submit(x, probs=True, value=True) for _ in range(_lib.BK_MAX_INFLIGHT)]
+    with pytest.raises(ValueError):
+        e.submit(x, probs=True, value=True)
+    for t in tickets:
+        e.wait(t)
+    s = e.stats()
+    assert s["evals"] >= 7 * (1 + _lib.BK_MAX_INFLIGHT) and s["max_batch_seen"] == 7
+    e.close()
