@@ -101,7 +101,10 @@ __device__ __forceinline__ void sched_pattern(std::integer_sequence<int, I...>) 
 
 // One conv layer for one wave.  acc[mt][nt]: 32 couts (rows) x 32 positions (columns).
 // wl: the layer's fp16 fragments [k16 step][cout tile (4)][piece hi/lo][lane][8], 8 KiB per step.
-template <int NB, bool FIRST>
+// NPROD = 3: w_hi x_hi + w_lo x_hi + w_hi x_lo.  NPROD = 2 drops the x_lo product (and its LDS reads):
+// only for layer 0 when every input plane value of the workgroup is exactly an fp16 (features()
+// planes are small integers, so in practice always).
+template <int NB, bool FIRST, int NPROD = 3>
 __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* __restrict__ wl,
                                              f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
     constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
@@ -162,7 +165,7 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
         for (int mt = 0; mt < MTW; ++mt) {
             const char* p = actb + (ab[mt] + (gb ^ swb[mt]));
             X[mt][0] = *reinterpret_cast<const f16x8*>(p);
-            X[mt][1] = *reinterpret_cast<const f16x8*>(p + LO);
+            if (NPROD == 3) X[mt][1] = *reinterpret_cast<const f16x8*>(p + LO);
         }
     };
 
@@ -177,14 +180,15 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][0], acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], X[mt][0], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][1], acc[mt][nt], 0, 0, 0);
+                if (NPROD == 3)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][1], acc[mt][nt], 0, 0, 0);
             }
     };
 
     // step ks: X(ks+1) is read from LDS and W(ks+3) fetched from L2 while step ks's MFMAs run
     auto step = [&](auto MLO, auto MHI, int ks, const f16x8 (&Xc)[MTW][2], f16x8 (&Xn)[MTW][2],
                     const f16x8 (&Wc)[NT][2], f16x8 (&Wn3)[NT][2], bool may_cross) {
-        constexpr int NMFMA = 3 * (decltype(MHI)::value - decltype(MLO)::value) * NT;
+        constexpr int NMFMA = NPROD * (decltype(MHI)::value - decltype(MLO)::value) * NT;
 #if BK_EXP == 2   // timing experiment: no weight traffic in the loop (results are wrong)
         (void)Wn3;
 #else
@@ -198,7 +202,7 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
         read_x(Xn, kn % S);
 #endif
         mma(MLO, MHI, Xc, Wc);
-        sched_pattern<NMFMA, 2 * MTW, 2 * NT>(std::make_integer_sequence<int, 2 * MTW>{});
+        sched_pattern<NMFMA, (NPROD == 3 ? 2 : 1) * MTW, 2 * NT>(std::make_integer_sequence<int, (NPROD == 3 ? 2 : 1) * MTW>{});
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -228,6 +232,15 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
         } else {
             run(I0{}, IM{}, 0, 48);
             run(I0{}, std::integral_constant<int, MTW - 1>{}, 48, 72);  // tile 7 = y=8 points: dy=+1 is all halo
+        }
+    } else if constexpr (NB == 3 && FIRST) {
+        // 5x5: taps ky=0,1 are steps [0,20), ky=3,4 steps [30,50); ranges must be multiples of 4
+        if (wm == 0) {
+            run(std::integral_constant<int, 1>{}, IM{}, 0, 20);   // dy=-2,-1 read only halo for the y=0 rows
+            run(I0{}, IM{}, 20, NSTEPS);
+        } else {
+            run(I0{}, IM{}, 0, 32);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 32, NSTEPS);  // dy=+1,+2: only halo for the y=8 rows
         }
     } else {
         run(I0{}, IM{}, 0, NSTEPS);
@@ -267,6 +280,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     // ---- stage the feature planes as fp16 hi/lo: NCHW global -> [pos][hi 4x8 | lo 4x8] ----
     for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    bool inexact = false;
     if (tid < nb * 81) {
         // one thread per position: 27 channel loads (coalesced across threads: consecutive points of a
         // plane), split into fp16 hi/lo, stored as 4 groups x (16 B hi + 16 B lo)
@@ -291,13 +305,15 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
             for (int j = 0; j < 8; ++j) {
                 hi[j] = (_Float16)v[8 * g + j];
                 lo[j] = (_Float16)(v[8 * g + j] - (float)hi[j]);
+                inexact |= lo[j] != (_Float16)0.f;
             }
             char* d = actb + p * 128 + ((g ^ ((p >> 1) & 3)) << 4);
             *reinterpret_cast<f16x8*>(d) = hi;
             *reinterpret_cast<f16x8*>(d + 64) = lo;
         }
     }
-    __syncthreads();
+    // barrier + workgroup-wide OR: does any input need its lo half?
+    const bool need_lo = __syncthreads_or(inexact ? 1 : 0) != 0;
 
     STAMP(1);
     f32x16 acc[MTW][NT];
@@ -342,7 +358,8 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     };
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer16<NB, true>(actb, P.wfrag16, acc, lane, wm, wn);
+    if (need_lo) conv_layer16<NB, true, 3>(actb, P.wfrag16, acc, lane, wm, wn);
+    else conv_layer16<NB, true, 2>(actb, P.wfrag16, acc, lane, wm, wn);
     STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};

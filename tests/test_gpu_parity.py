@@ -203,3 +203,18 @@ def test_abi_edge_cases(weights, gold):
     s = e.stats()
     assert s["evals"] >= 7 * (1 + _lib.BK_MAX_INFLIGHT) and s["max_batch_seen"] == 7
     e.close()
+
+
+def test_non_integer_inputs_use_the_lo_half(weights, oracle):
+    """Planes that are not exactly representable in fp16 (the reference never produces them, a generic
+    caller might): layer 0 must then keep the x_lo product; checked against the oracle."""
+    from bokego_amd.engine import LeafEngine
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 8, size=(7, 27, 9, 9)) * (rng.random((7, 27, 9, 9)) < 0.12)).astype(np.float32)
+    x += (rng.random(x.shape).astype(np.float32) * 1e-3) * (x > 0)       # 7.0003..., needs 22 bits
+    e = LeafEngine(weights[0], weights[1], max_batch=8, precision="f16x2")
+    out = e.eval(x, logits=True, probs=False, value=True)
+    lg = oracle[0](x)
+    assert np.abs(out["logits"] - lg).max() < 1e-4 * max(1.0, np.abs(lg).max() / 50)
+    assert np.abs(out["value"] - oracle[1](x)).max() < 1e-4
+    e.close()
