@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "bk_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -75,6 +77,29 @@ struct Geo {
     static constexpr int LDS_BYTES = (NPOS * 128 + DUMMY_FLOATS + HS_FLOATS) * 4;
 };
 
+// Flat GEMM row r of the workgroup -> board point.  NB == 3 orders the rows y-major so that tile 0
+// holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding rows
+// each; tiles 1..6 the 189 points with y in 1..7 + 3 padding rows): a tap with dy<0 reads only zero
+// halo for tile 0 and one with dy>0 only zero halo for tile 7, so those MFMAs are skipped.
+// constexpr: the epilogue uses it at compile time, the A-fragment addressing at run time.
+template <int NB>
+struct RowMap {
+    static constexpr bool valid(int r) {
+        return NB == 3 ? (r < 32 ? r < 27 : r < 224 ? r - 32 < 189 : r - 224 < 27) : r < 81 * NB;
+    }
+    static constexpr int b(int r) {
+        return !valid(r) ? 0 : NB == 3 ? (r < 32 ? r / 9 : r < 224 ? (r - 32) / 63 : (r - 224) / 9) : r / 81;
+    }
+    static constexpr int y(int r) {
+        return !valid(r) ? 4 : NB == 3 ? (r < 32 ? 0 : r < 224 ? 1 + ((r - 32) % 63) / 9 : 8) : (r % 81) / 9;
+    }
+    static constexpr int x(int r) {
+        return !valid(r) ? 0 : NB == 3 ? (r < 32 ? r % 9 : r < 224 ? ((r - 32) % 63) % 9 : (r - 224) % 9) : (r % 81) % 9;
+    }
+    static constexpr int flat(int r) { return 81 * b(r) + 9 * y(r) + x(r); }              // swizzle key source
+    static constexpr int pos(int r) { return (10 * b(r) + 1 + y(r)) * 10 + x(r) + 1; }   // 128-channel layout
+};
+
 // One conv layer for one wave: acc[mt][nt] (32 rows x 32 couts each) = sum over taps, cin.
 // wl: the layer's fragment-ordered weights [tap][group of 8 cin][cout tile (4)][lane][4].
 template <int NB, bool FIRST>
@@ -86,13 +111,13 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
     constexpr int NBLK = FIRST ? 1 : 4;  // blocks of 4 channel-groups (8 cin each) per tap
     const int h = lane >> 5, l32 = lane & 31;
 
-    int pbase[MTW];
+    int pbase[MTW], rrow[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        int r = (wm * MTW + mt) * 32 + l32;
-        if (r >= 81 * NB) r = 0;  // padding rows compute garbage from a valid address; never stored
-        const int b = r / 81, q = r - 81 * b, y = q / 9, x = q - 9 * y;
+        const int r = (wm * MTW + mt) * 32 + l32;  // padding rows map to a valid point; never stored
+        const int b = RowMap<NB>::b(r), y = RowMap<NB>::y(r), x = RowMap<NB>::x(r);
         pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
+        rrow[mt] = 81 * b + 9 * y + x;
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -125,7 +150,10 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
         for (int mt = 0; mt < MTW; ++mt) {
             const int pa = pbase[mt] + off;
             ab[mt] = FIRST ? pa * 128 : pa * 512;
-            swb[mt] = (FIRST ? ((pa >> 1) & 7) : (pa & 15)) << 4;
+            // swizzle key of the position being read = low bits of ITS flat index r + 9dy + dx (the
+            // writer's key): the 16 lanes of a ds_read_b128 group hit 16 distinct slots.  Out-of-board
+            // neighbours land in all-zero halo rows, where any key reads zeros.
+            swb[mt] = (FIRST ? ((pa >> 1) & 7) : ((rrow[mt] + 9 * (ky - 1) + (kx - 1)) & 15)) << 4;
         }
     };
     const int hb = h << 4;
@@ -143,7 +171,9 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
 
     // one block = 4 groups; `blk` is the block's index in the layer, Bc its fragments, Bn receives
     // the next block's.  Group parity alternates A0/A1; a block has an even number of groups.
-    auto do_block = [&](int blk, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT]) {
+    // MLO..MHI: the row tiles of this wave that take part (zero-halo tap skipping, see RowMap)
+    auto do_block = [&](auto MLO, auto MHI, int blk, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT]) {
+        constexpr int mlo = decltype(MLO)::value, mhi = decltype(MHI)::value;
         load_b(Bn, blk + 1);  // the last block over-reads into the next layer / the pad: harmless
         __builtin_amdgcn_sched_barrier(0);
         const int gb = NBLK == 1 ? 0 : (blk & (NBLK - 1));
@@ -165,7 +195,7 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
                 chunkb = ((gb * 4 + gg + 1) << 5) | hb;
             }
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+            for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][0], Bc[gg][nt][0], acc[mt][nt], 0, 0, 0);
@@ -174,27 +204,50 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
 #pragma unroll
             for (int j = 1; j < 4; ++j)
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
+                for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][j], Bc[gg][nt][j], acc[mt][nt], 0, 0, 0);
         }
     };
 
+    // blocks [b0, b1), b0 even, with one tile range; the operand pipelines run across calls
+    auto run = [&](auto MLO, auto MHI, int b0, int b1) {
+#pragma unroll 1
+        for (int blk = b0; blk + 1 < b1; blk += 2) {
+            do_block(MLO, MHI, blk, B0, B1);
+            do_block(MLO, MHI, blk + 1, B1, B0);
+        }
+        if ((b1 - b0) & 1) do_block(MLO, MHI, b1 - 1, B0, B1);
+    };
+
     load_b(B0, 0);
     tap_setup(0);
     read_a(A0, hb);
-#pragma unroll 1
-    for (int blk = 0; blk + 1 < NBLOCKS; blk += 2) {
-        do_block(blk, B0, B1);
-        do_block(blk + 1, B1, B0);
+    using I0 = std::integral_constant<int, 0>;
+    using IM = std::integral_constant<int, MTW>;
+    if constexpr (NB == 3 && !FIRST) {
+        // 4 blocks per tap: ky=0 is blocks [0,12), ky=2 blocks [24,36)
+        if (wm == 0) {
+            run(std::integral_constant<int, 1>{}, IM{}, 0, 12);
+            run(I0{}, IM{}, 12, NBLOCKS);
+        } else {
+            run(I0{}, IM{}, 0, 24);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 24, NBLOCKS);
+        }
+    } else if constexpr (NB == 3 && FIRST) {
+        // 1 block per tap: ky=0,1 are blocks [0,10), ky=3,4 blocks [15,25); ranges start at even blocks
+        if (wm == 0) {
+            run(std::integral_constant<int, 1>{}, IM{}, 0, 10);
+            run(I0{}, IM{}, 10, NBLOCKS);
+        } else {
+            run(I0{}, IM{}, 0, 16);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 16, NBLOCKS);
+        }
+    } else {
+        run(I0{}, IM{}, 0, NBLOCKS);
     }
-    if (NBLOCKS & 1) do_block(NBLOCKS - 1, B0, B1);
 }
-
-// position of flat row r (board r/81, point r%81) in the 128-channel layout; constexpr so the
-// epilogue's addresses are immediates
-constexpr int row_pos3(int r) { return (10 * (r / 81) + 1 + (r % 81) / 9) * 10 + (r % 81) % 9 + 1; }
 
 // bias + ReLU + in-place store of this wave's tiles.  Accumulator register i of row tile T holds
 // row T*32 + (i&3) + 8*(i>>2) + 4*h (h = lane>>5): with the wave's row block WMI a template
@@ -214,11 +267,12 @@ __device__ __forceinline__ void store_tiles(float* act, int dummy_addr, const f3
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int r0 = (WMI * MTW + mt) * 32 + (i & 3) + 8 * (i >> 2), r1 = r0 + 4;
-                const bool ok0 = r0 < 81 * NB, ok1 = r1 < 81 * NB;
-                const int p0 = ok0 ? row_pos3(r0) : 0, p1 = ok1 ? row_pos3(r1) : 0;
+                const int r0 = (WMI * MTW + mt) * 32 + (i & 3) + 8 * (i >> 2), r1 = r0 + 4;  // constants after unrolling
+                const bool ok0 = RowMap<NB>::valid(r0), ok1 = RowMap<NB>::valid(r1);
+                const int p0 = RowMap<NB>::pos(r0), p1 = RowMap<NB>::pos(r1);
+                const int k0 = RowMap<NB>::flat(r0) & 15, k1 = RowMap<NB>::flat(r1) & 15;
                 const int base = h ? p1 * 128 : p0 * 128;
-                const int swz = h ? (p1 & 15) : (p0 & 15);
+                const int swz = h ? k1 : k0;
                 int addr = base + (((cchunk ^ swz) << 2) | clow);
                 if (!(ok0 && ok1)) addr = (h ? ok1 : ok0) ? addr : dummy_addr;
                 const float v = acc[mt][nt][i] + bv;
@@ -344,7 +398,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
                 const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
 #pragma unroll 8
                 for (int cc = 0; cc < 32; ++cc) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(act + p * 128 + ((cc ^ (p & 15)) << 2));
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(act + p * 128 + ((cc ^ ((81 * wave + q) & 15)) << 2));
                     const f32x4 w = hw[cc];
                     d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
                 }
