@@ -67,157 +67,185 @@ class _GTPProtocol:
         self.running = False
 
     # ---- protocol ------------------------------------------------------------------------------------
+    # Every command is a handler `_c_<name>(args, ctx) -> (ok, text)`; send() does the framing.
+    # ctx.turn is the root's turn when the command arrived.
     def send(self, cmd):
-        """One GTP command -> reply string "=id text\\n\\n" / "?id text\\n\\n" (reference gtp.py:110-330)."""
+        """One GTP command -> reply string "=id text\n\n" / "?id text\n\n" (reference gtp.py:110-330)."""
         if not self.running or not cmd:
             return None
-        valid, out, cmd_id = False, "", ""
-        cmd = cmd.lower().split()
-        if re.match(r"\d+", cmd[0]):
-            cmd_id, cmd = cmd[0], cmd[1:]
-        this_turn = self.root.turn
-        c = cmd[0]
+        words = cmd.lower().split()
+        cmd_id = ""
+        if re.match(r"\d+", words[0]):
+            cmd_id, words = words[0], words[1:]
+        name, args = words[0], words[1:]
+        if name not in self.commands:
+            ok, text = False, f"unknown command '{name}'"
+        else:
+            res = getattr(self, "_c_" + name)(args, self.root.turn)
+            if not isinstance(res, tuple):
+                return res                      # analyze: a generator of info lines
+            ok, text = res
+        return f"{'=' if ok else '?'}{cmd_id} {text}\n\n"
 
-        if c not in _GTPProtocol.commands:
-            out = f"unknown command '{c}'"
-        elif c == "protocol_version":
-            out, valid = "2", True
-        elif c == "version":
-            out, valid = "0.3", True
-        elif c == "name":
-            out, valid = "boke", True
-        elif c == "known_command":
-            if len(cmd) == 2:
-                out, valid = ("true" if cmd[1] in _GTPProtocol.commands else "false"), True
-        elif c == "boardsize":
-            if len(cmd) != 2 or cmd[1] != "9":
-                out = "boke only plays on 9x9 board"
+    @staticmethod
+    def _side(word):
+        """0 for black, 1 for white ('b', 'black', 'w', 'white')."""
+        return 0 if "b" in word else 1
+
+    def _c_protocol_version(self, args, turn):
+        return True, "2"
+
+    def _c_version(self, args, turn):
+        return True, "0.3"
+
+    def _c_name(self, args, turn):
+        return True, "boke"
+
+    def _c_known_command(self, args, turn):
+        if len(args) != 1:
+            return False, ""
+        return True, "true" if args[0] in self.commands else "false"
+
+    def _c_list_commands(self, args, turn):
+        return True, "\n".join(self.commands)
+
+    _c_help = _c_list_commands
+
+    def _c_boardsize(self, args, turn):
+        if args != ["9"]:
+            return False, "boke only plays on 9x9 board"
+        return True, ""
+
+    def _c_clear_board(self, args, turn):
+        self.set_root(self._node())
+        return True, ""
+
+    def _c_komi(self, args, turn):
+        if not args:
+            return False, "usage: komi <num-komi>"
+        try:
+            self.root.komi = float(args[0])
+        except ValueError:
+            return False, "invalid komi value"
+        return True, ""
+
+    def _c_play(self, args, turn):
+        if len(args) < 2 or args[0] not in self.colors:
+            return False, "usage: play <color> <vertex>"
+        if args[1] == "resign":
+            self.running = False
+            return True, ""
+        try:
+            mv = go.squash(args[1])
+        except (ValueError, IndexError):
+            return False, "invalid coordinate"
+        try:
+            if self._side(args[0]) != turn % 2:   # same colour twice in a row: a pass goes in between
+                passed = self.root.make_move(go.PASS)
+                if not passed.is_legal(mv):
+                    return False, "illegal move"
+                self._last_root = self.root
+                self.set_root(passed.make_move(mv))
+                self._move_history.append(mv)
+                self._undid = False
             else:
-                valid = True
-        elif c == "clear_board":
-            self.set_root(self._node())
-            valid = True
-        elif c == "komi":
-            if len(cmd) < 2:
-                out = "usage: komi <num-komi>"
-            else:
-                try:
-                    self.root.komi = float(cmd[1])
-                    valid = True
-                except ValueError:
-                    out = "invalid komi value"
-        elif c == "play":
-            if len(cmd) < 3 or cmd[1] not in _GTPProtocol.colors:
-                out = "usage: play <color> <vertex>"
-            elif cmd[2] == "resign":
-                valid, self.running = True, False
-            else:
-                try:
-                    mv = go.squash(cmd[2])
-                except (ValueError, IndexError):
-                    mv, out = None, "invalid coordinate"
-                if mv is not None:
-                    turn = 0 if "b" in cmd[1] else 1
-                    if turn != this_turn % 2:      # same colour twice in a row: a pass is inserted
-                        new = self.root.make_move(go.PASS)
-                        if new.is_legal(mv):
-                            self._last_root = self.root
-                            self.set_root(new.make_move(mv))
-                            self._move_history.append(mv)
-                            self._undid = False
-                            valid = True
-                        else:
-                            out = "illegal move"
-                    else:
-                        try:
-                            self.input_move(mv)
-                            valid = True
-                        except go.IllegalMove:
-                            out = "illegal move"
-        elif c == "showboard":
-            out, valid = "\n" + str(self.root), True
-        elif c in ("genmove", "reg_genmove"):
-            if len(cmd) != 2 or cmd[1] not in _GTPProtocol.colors:
-                out = f"usage: {c} <color>"
-            else:
-                turn = 0 if "b" in cmd[1] else 1
-                if turn != this_turn % 2:
-                    self.input_move(go.PASS)
-                    self._undid = True
-                mv = self.genmove(False if c == "reg_genmove" else None)
-                if mv == go.RESIGN:
-                    out, self.running = "resign", False
-                else:
-                    out = go.unsquash(mv)
-                valid = True
-        elif c == "undo":
-            if self._undid or self._last_root is None:
-                out = "cannot undo"
-            else:
-                self.set_root(self._last_root)
-                self._move_history.pop()
-                self._last_root, self._undid, valid = None, True, True
-        elif c == "last_move":
-            mv = self.root.last_move
-            if mv is None:
-                out = "no previous move known"
-            else:
-                out, valid = ("black " if this_turn % 2 == 1 else "white ") + go.unsquash(mv), True
-        elif c == "quit":
-            self.running, valid = False, True
-        elif c in ("help", "list_commands"):
-            out, valid = "\n".join(_GTPProtocol.commands), True
-        elif c == "clear_cache":
-            self.clear_cache()
-            self._undid, valid = True, True
-        elif c == "final_score":
-            score = self.root.score()
-            out = "0" if abs(score) < 1e-4 else (f"B+{score}" if score > 0 else f"W+{-score}")
-            valid = True
-        elif c == "move_history":
-            out, valid = "\n".join(go.unsquash(self._move_history)), True
-        elif c == "set_fixed_handicap":
-            if len(cmd) != 2 or not cmd[1].isnumeric():
-                out = "usage: set_fixed_handicap <num-handicaps>"
-            elif self.root.board != go.EMPTY_BOARD:
-                out = "board is not empty"
-            elif not 1 < int(cmd[1]) <= 5:
-                out = "invalid number of handicaps"
-            else:
-                stones = FLOWERS9[:int(cmd[1])]
-                board = "".join(go.BLACK if i in stones else go.EMPTY for i in range(81))
-                self.set_root(self._node(board=board, turn=1))
-                out, valid = " ".join(go.unsquash(list(stones))), True
-        elif c == "printsgf":
-            path = cmd[1] if len(cmd) == 2 else os.path.join(os.getcwd(), "bokego.sgf")
-            out, valid = go.write_sgf(self._move_history, path, komi=self.root.komi), True
-        elif c == "loadsgf":
-            if len(cmd) != 3 or not cmd[2].isnumeric():
-                out = "usage: loadsgf <path-to-sgf> <move-number>"
-            else:
-                try:
-                    for mv in go.get_moves(cmd[1]):
-                        self.input_move(mv)
-                    out, valid = ("black" if (int(cmd[2]) - 1) % 2 == 0 else "white"), True
-                except IOError as e:
-                    out = str(e)
-                except go.IllegalMove:
-                    out = "illegal move in sgf"
-        elif c == "analyze":
-            if len(cmd) != 3 or cmd[1] not in _GTPProtocol.colors or not cmd[2].isnumeric():
-                out = "usage: analyze <color> <interval>"
-            elif (0 if "b" in cmd[1] else 1) != this_turn % 2:
-                out = f"it is not {cmd[1]}'s turn"
-            elif not hasattr(self, "N"):
-                out = "analyze needs the Python tree (start without --native)"
-            else:
-                return self.analyze(int(cmd[2]))
-        elif c == "pondering":
-            if len(cmd) != 2 or cmd[1] not in ("on", "off"):
-                out = "usage: pondering <on/off>"
-            else:
-                self.pondering, valid = cmd[1] == "on", True
-        return f"{'=' if valid else '?'}{cmd_id} {out}\n\n"
+                self.input_move(mv)
+        except go.IllegalMove:
+            return False, "illegal move"
+        return True, ""
+
+    def _c_showboard(self, args, turn):
+        return True, "\n" + str(self.root)
+
+    def _c_genmove(self, args, turn, may_resign=True):
+        if len(args) != 1 or args[0] not in self.colors:
+            return False, "usage: " + ("genmove" if may_resign else "reg_genmove") + " <color>"
+        if self._side(args[0]) != turn % 2:
+            self.input_move(go.PASS)
+            self._undid = True
+        mv = self.genmove(None if may_resign else False)
+        if mv == go.RESIGN:
+            self.running = False
+            return True, "resign"
+        return True, go.unsquash(mv)
+
+    def _c_reg_genmove(self, args, turn):
+        return self._c_genmove(args, turn, may_resign=False)
+
+    def _c_undo(self, args, turn):
+        if self._undid or self._last_root is None:     # one level only, like the reference
+            return False, "cannot undo"
+        self.set_root(self._last_root)
+        self._move_history.pop()
+        self._last_root, self._undid = None, True
+        return True, ""
+
+    def _c_last_move(self, args, turn):
+        mv = self.root.last_move
+        if mv is None:
+            return False, "no previous move known"
+        return True, ("black " if turn % 2 == 1 else "white ") + go.unsquash(mv)
+
+    def _c_move_history(self, args, turn):
+        return True, "\n".join(go.unsquash(self._move_history))
+
+    def _c_quit(self, args, turn):
+        self.running = False
+        return True, ""
+
+    def _c_clear_cache(self, args, turn):
+        self.clear_cache()
+        self._undid = True
+        return True, ""
+
+    def _c_final_score(self, args, turn):
+        score = self.root.score()
+        if abs(score) < 1e-4:
+            return True, "0"
+        return True, f"B+{score}" if score > 0 else f"W+{-score}"
+
+    def _c_set_fixed_handicap(self, args, turn):
+        if len(args) != 1 or not args[0].isnumeric():
+            return False, "usage: set_fixed_handicap <num-handicaps>"
+        if self.root.board != go.EMPTY_BOARD:
+            return False, "board is not empty"
+        n = int(args[0])
+        if not 1 < n <= 5:
+            return False, "invalid number of handicaps"
+        stones = FLOWERS9[:n]
+        self.set_root(self._node(board="".join(go.BLACK if i in stones else go.EMPTY for i in range(81)), turn=1))
+        return True, " ".join(go.unsquash(list(stones)))
+
+    def _c_printsgf(self, args, turn):
+        path = args[0] if len(args) == 1 else os.path.join(os.getcwd(), "bokego.sgf")
+        return True, go.write_sgf(self._move_history, path, komi=self.root.komi)
+
+    def _c_loadsgf(self, args, turn):
+        if len(args) != 2 or not args[1].isnumeric():
+            return False, "usage: loadsgf <path-to-sgf> <move-number>"
+        try:
+            for mv in go.get_moves(args[0]):
+                self.input_move(mv)
+        except IOError as e:
+            return False, str(e)
+        except go.IllegalMove:
+            return False, "illegal move in sgf"
+        return True, "black" if (int(args[1]) - 1) % 2 == 0 else "white"
+
+    def _c_analyze(self, args, turn):
+        if len(args) != 2 or args[0] not in self.colors or not args[1].isnumeric():
+            return False, "usage: analyze <color> <interval>"
+        if self._side(args[0]) != turn % 2:
+            return False, f"it is not {args[0]}'s turn"
+        if not hasattr(self, "N"):
+            return False, "analyze needs the Python tree (start with --python-tree)"
+        return self.analyze(int(args[1]))
+
+    def _c_pondering(self, args, turn):
+        if len(args) != 1 or args[0] not in ("on", "off"):
+            return False, "usage: pondering <on/off>"
+        self.pondering = args[0] == "on"
+        return True, ""
 
     # ---- engine side ---------------------------------------------------------------------------------
     def input_move(self, sq_c):
