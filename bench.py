@@ -30,14 +30,13 @@ BYTES_PER_LEAF = 8748 + 328          # compulsory HBM bytes (f32 planes in, 81 p
 BATCH = 4096
 
 
-def make_workload(B, seed):
-    """Synthetic batch: seeded resample of the golden feature planes (real game + random-playout
-    positions encoded by the reference's features()); dense-conv cost is data independent."""
-    g = os.path.join(REPO, "tests", "golden")
-    pool = np.concatenate([np.load(os.path.join(g, "features.npz"))["incremental"],
-                           np.load(os.path.join(g, "playouts.npz"))["features"]])
-    idx = np.random.default_rng(seed).integers(0, len(pool), size=B)
-    return pool[idx].astype(np.float32)
+def make_workload(B, rank):
+    """SURVEY 8d config-2 input: position i is a seeded random playout from the empty board
+    (rng = default_rng(20260 + i), L = rng.integers(0, 61) uniformly random legal non-eye-filling
+    moves) encoded by the build's own board engine in incremental mode -> f32 [B,27,9,9].  The recipe
+    is pinned move-for-move against the reference's rules engine by tests/golden/playouts.json."""
+    from bokego_amd.workload import make_batch
+    return make_batch(B, seed_base=20260 + rank * B, dtype=np.float32)
 
 
 def measured_traffic(batch):
@@ -101,7 +100,7 @@ def main():
     g = os.path.join(REPO, "tests", "golden")
     pw, vw = load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw"))
     eng = LeafEngine(pw, vw, device_id=local_rank, max_batch=args.batch, precision=args.precision)
-    x_host = make_workload(args.batch, 20260 + rank)
+    x_host = make_workload(args.batch, rank)
     x = torch.from_numpy(x_host).cuda()
 
     def barrier():
@@ -169,7 +168,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16x2 (fp16 hi/lo split operands = 22-bit significands, fp32 accumulate)" if f16 else "f32",
-            "data": "synthetic",
+            "data": "synthetic (seeded random-playout positions, SURVEY 8d recipe)",
             "config": {"workload": f"configs[1]: batch={args.batch} 9x9 positions, PolicyNet logits+softmax and "
                                    "ValueNet, device-resident inputs/outputs",
                        "batch_per_gpu": args.batch, "weights": "policy_19 + value_synth (tests/golden)",
