@@ -181,6 +181,10 @@ def main():
                          "algorithmic_flop_per_launch": args.batch * FLOP_PER_LEAF,
                          "algorithmic_hbm_bytes_per_launch": args.batch * BYTES_PER_LEAF,
                          "executed_mfma_flop_per_algorithmic_flop": 3.0 if f16 else 1.0,
+                         # what the matrix unit really issued: per 3-board task and net 41,024 MFMAs of
+                         # 32x32x16 (3x3 layers: 3 products, zero-halo taps skipped; layer 0: 2 products)
+                         "executed_mfma_tflops": (2 * ((args.batch + 2) // 3) * 41024 * 32768 / (kern_ms * 1e-3) / 1e12)
+                         if f16 and args.batch >= 768 else None,
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
             "host_buffer_e2e_leaf_evals_per_s": e2e,

@@ -455,7 +455,10 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
 
 template <int NB>
 hipError_t launch16_nb(const bk_eval_args& a, hipStream_t stream) {
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};  // the attribute is per device: one flag per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    bool& attr_set = attr_set_dev[dev];
     auto kern = bk_leaf_eval_f16_kernel<NB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
