@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfplay", action="store_true", help="skip the secondary config-4 measurement")
     ap.add_argument("--precision", choices=["f16x2", "f32"], default=os.environ.get("BK_PRECISION", "f16x2"),
                     help="conv arithmetic: fp16 hi/lo split operands with fp32 accumulation (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -149,6 +150,25 @@ def main():
         eng.wait(pend.pop(0))
         e2e_u8 = 8 * args.batch / (time.perf_counter() - t1)
 
+    # Secondary measurement (outside the timed region above): BASELINE config 4 -- 512 self-play games,
+    # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
+    sp = None
+    if not args.no_selfplay:
+        from bokego_amd import selfplay
+        ev = selfplay.EngineEvaluator(eng)
+        barrier()
+        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=args.batch,
+                                          reduce_device=torch.device("cuda", local_rank))
+        secs = local["seconds"]
+        if dist is not None:
+            t = torch.tensor([secs], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
+        sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus", "games": total["games"],
+              "games_per_min": total["games"] / secs * 60, "seconds": secs, "plies": total["plies"],
+              "value_evals_per_s": total["value_evals"] / secs, "black_wins": total["black_wins"],
+              "stats_allreduce_ms": local["allreduce_s"] * 1e3, "collective": "1 all-reduce of 89 doubles per generation"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pw, vw, x_host)
@@ -187,6 +207,7 @@ def main():
                          if f16 and args.batch >= 768 else None,
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
+            "selfplay": sp,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,
         }

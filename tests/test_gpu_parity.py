@@ -218,3 +218,21 @@ def test_non_integer_inputs_use_the_lo_half(weights, oracle):
     assert np.abs(out["logits"] - lg).max() < 1e-4 * max(1.0, np.abs(lg).max() / 50)
     assert np.abs(out["value"] - oracle[1](x)).max() < 1e-4
     e.close()
+
+
+def test_c_abi_from_plain_c(gold):
+    """examples/bk_demo.c: a C program (no Python, no torch) loads BKW1 weights, encodes the empty board with
+    libbkgo, evaluates it through bk_eval and prints the SURVEY 8c known answers."""
+    import subprocess
+    from conftest import REPO
+    exe = os.path.join(REPO, "examples", "bk_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "bokego_amd", "csrc"), "demo"])
+    out = subprocess.run([exe, os.path.join(GOLDEN, "policy_19.bkw"), os.path.join(GOLDEN, "value_synth.bkw")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "best move E5 (index 40)" in out.stdout
+    p = float(out.stdout.split("p=")[1].split()[0])
+    v = float(out.stdout.split("value=")[1].split()[0])
+    f, n = gold
+    assert abs(p - 0.818645) < 1e-5 and abs(v - float(n["values_b1"][0])) < 1e-4

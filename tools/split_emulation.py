@@ -50,3 +50,12 @@ for name,mode,dt in [
     sa,sw=(16.0,4096.0) if dt==torch.float16 else (1.0,1.0)
     y=run(sd,mode,sa,sw,dt)
     print('%-26s split-induced max|dlogit| %.3g   vs goldens %.3g'%(name,np.abs(y-ex).max(),np.abs(y-gold['logits_b1']).max()))
+
+# ---- can some layers live with 2 products? --------------------------------------------------------
+print()
+for name, mode in [
+    ('f16 w22 x a11 (hh+lh), all layers', (1, 2, [(0, 0), (0, 1)])),
+    ('f16 w11 x a22 (hh+hl), all layers', (2, 1, [(0, 0), (1, 0)])),
+]:
+    y = run(sd, mode, 16.0, 4096.0, torch.float16)
+    print('%-36s split-induced max|dlogit| %.3g   vs goldens %.3g' % (name, np.abs(y - ex).max(), np.abs(y - gold['logits_b1']).max()))
