@@ -248,10 +248,10 @@ def pool_stats(pools):
 
 
 def all_reduce_stats(stats, device=None):
-    """The generation's single collective: sum the statistics vector over ranks (world 1: no-op)."""
+    """The generation's single collective: sum the statistics vector over ranks (no process group: no-op)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return stats, 0.0
     t = torch.from_numpy(stats.copy())
     if device is not None:
