@@ -129,6 +129,16 @@ def main():
     kern_ms = (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])
     assert torch.isfinite(out["value"]).all() and torch.isfinite(out["probs"]).all()
 
+    # per-launch spread (median and p10/p90), one launch at a time, outside the timed region
+    eng.set_profiling(True)
+    each = []
+    for _ in range(min(100, max(10, args.steps))):
+        eng.eval_device(x, logits=True, probs=True, value=True)
+        torch.cuda.synchronize()
+        each.append(eng.stats()["last_kernel_ms"])
+    eng.set_profiling(False)
+    p10, p50, p90 = (float(np.percentile(each, q)) for q in (10, 50, 90))
+
     # PCIe-inclusive rates through the host-buffer ABI (reported beside, never as `value`):
     # (a) synchronous bk_eval with f32 planes, as the reference's host tensors would arrive;
     # (b) what the ABI is built for: uint8 planes, two tickets in flight (H2D of one batch under the
@@ -157,7 +167,8 @@ def main():
         from bokego_amd import selfplay
         ev = selfplay.EngineEvaluator(eng)
         barrier()
-        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=args.batch,
+        threads = max(1, min(16, len(os.sched_getaffinity(0)) // world))  # host cores are shared by the ranks
+        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=args.batch, threads=threads,
                                           reduce_device=torch.device("cuda", local_rank))
         secs = local["seconds"]
         if dist is not None:
@@ -167,7 +178,7 @@ def main():
         sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus", "games": total["games"],
               "games_per_min": total["games"] / secs * 60, "seconds": secs, "plies": total["plies"],
               "value_evals_per_s": total["value_evals"] / secs, "black_wins": total["black_wins"],
-              "stats_allreduce_ms": local["allreduce_s"] * 1e3, "collective": "1 all-reduce of 89 doubles per generation"}
+              "stats_allreduce_ms": local["allreduce_s"] * 1e3, "host_threads_per_rank": threads, "collective": "1 all-reduce of 89 doubles per generation"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -198,6 +209,7 @@ def main():
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "bk_leaf_eval_f16_kernel<3>" if f16 else "bk_leaf_eval_kernel<3>",
                          "kernel_ms": kern_ms,
+                         "kernel_ms_isolated_p10_p50_p90": [p10, p50, p90],
                          "algorithmic_flop_per_launch": args.batch * FLOP_PER_LEAF,
                          "algorithmic_hbm_bytes_per_launch": args.batch * BYTES_PER_LEAF,
                          "executed_mfma_flop_per_algorithmic_flop": 3.0 if f16 else 1.0,

@@ -189,14 +189,14 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
     auto step = [&](auto MLO, auto MHI, int ks, const f16x8 (&Xc)[MTW][2], f16x8 (&Xn)[MTW][2],
                     const f16x8 (&Wc)[NT][2], f16x8 (&Wn3)[NT][2], bool may_cross) {
         constexpr int NMFMA = NPROD * (decltype(MHI)::value - decltype(MLO)::value) * NT;
-#if BK_EXP == 2   // timing experiment: no weight traffic in the loop (results are wrong)
+#if BK_EXP & 2   // timing experiment: no weight traffic in the loop (results are wrong)
         (void)Wn3;
 #else
         load_w(Wn3, ks + 3);
 #endif
         const int kn = ks + 1;
         if (may_cross && (kn % S) == 0) tap_setup(kn / S);
-#if BK_EXP == 1   // timing experiment: no LDS reads in the loop (results are wrong)
+#if BK_EXP & 1   // timing experiment: no LDS reads in the loop (results are wrong)
         (void)Xn;
 #else
         read_x(Xn, kn % S);
