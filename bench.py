@@ -7,10 +7,13 @@ positions, policy logits + softmax + value, inputs already resident in HBM.  Wit
 positions per step: the path shards with no data-path collective ("weak" scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline      bound = fp32 MFMA (266,838,272 algorithmic FLOP per leaf-eval,
-                peak 157.3 TFLOP/s), kernel time from HIP events on the launch stream
-  cpu_baseline  the CPU oracle (oracle/nnet_ref.c, a port of the reference's forward pass)
-                timed on this host's cores on a bounded sample of the same workload.
+  roofline      bound = MFMA: SURVEY 8d's 266,838,272 algorithmic FLOP per leaf-eval over the dense MFMA
+                peak of the dtype the matrix unit executes (2,500 TFLOP/s for the default f16x2 kernel,
+                157.3 for --precision f32); kernel time from HIP events on the launch stream
+  cpu_baseline  the CPU oracle (oracle/nnet_ref.c, a port of the reference's forward pass) timed on this
+                host's cores on a bounded sample of the same workload
+  selfplay      secondary, outside the timed region: BASELINE configs[3] (512 self-play games sharded over
+                the ranks + the end-of-generation all-reduce) with its own CPU baseline at N=1.
 """
 import argparse
 import json
@@ -67,6 +70,28 @@ def cpu_baseline(pw, vw, x, target_s=12.0):
     dt = time.time() - t0
     return {"value": reps * len(x) / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over the same {len(x)}-position batch, oracle/nnet_ref.c (OpenMP, fp32), {dt:.1f}s"}
+
+
+def selfplay_cpu_baseline(pw, vw, plies_per_game, moves=3, rollouts=400, cores=16):
+    """The reference's way of running config 4 on the host: one sequential tree per process, one position per
+    network call (oracle/mcts_ref.py + the C oracle nets, 1 thread).  Bounded sample: `moves` moves of one
+    game; games/min is extrapolated to `cores` independent single-thread games."""
+    from oracle import oracle
+    from oracle.mcts_ref import RefMCTS
+    oracle.set_threads(1)
+    P, V = oracle.OraclePolicy(pw), oracle.OracleValue(vw)
+    t0 = time.perf_counter()
+    m = RefMCTS(lambda f: P(f), lambda f: V(f))
+    for _ in range(moves):
+        m.rollout(rollouts)
+        m.choose()
+    s_per_move = (time.perf_counter() - t0) / moves
+    cores = min(cores, len(os.sched_getaffinity(0)))
+    oracle.set_threads(cores)
+    return {"games_per_min": 60.0 / (plies_per_game * s_per_move) * cores, "unit": "games/min", "cores": cores, "kind": "port",
+            "s_per_move_one_core": s_per_move,
+            "sample": f"{moves} moves x {rollouts} rollouts of one sequential tree on 1 core (batch-1 network calls), "
+                      f"extrapolated to {plies_per_game:.0f} plies/game and {cores} independent games"}
 
 
 def main():
@@ -183,6 +208,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pw, vw, x_host)
+        if sp is not None:
+            sp["cpu_baseline"] = selfplay_cpu_baseline(pw, vw, sp["plies"] / max(1.0, sp["games"]))
 
     if rank == 0:
         value = world * args.batch * args.steps / dt
