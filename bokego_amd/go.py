@@ -18,7 +18,7 @@ RESIGN = -2
 _NO_MOVE = -3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GO_LIB_PATH = os.path.join(_HERE, "libbkgo.so")
+GO_LIB_PATH = os.environ.get("BK_GO_LIB_PATH") or os.path.join(_HERE, "libbkgo.so")  # BK_GO_LIB_PATH: sanitizer builds
 
 
 class Pos(ctypes.Structure):
