@@ -36,7 +36,9 @@ struct Slot {  // one in-flight host-buffer request
     unsigned int* d_flag = nullptr;  // f16x2 overflow flag of this request
     unsigned int* h_flag = nullptr;
     int dtype = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t in_ready = nullptr;   // H2D of this request finished (copy-in stream)
+    hipEvent_t computed = nullptr;   // kernel of this request finished (compute stream)
+    hipEvent_t done = nullptr;       // D2H of this request finished (copy-out stream)
     bool busy = false;
 };
 
@@ -48,7 +50,10 @@ struct bk_engine {
     int n_cu = 256;
     bool has_policy = false, has_value = false;
     int precision = BK_PRECISION_F16X2;
-    hipStream_t stream = nullptr;
+    // ticket path: H2D, kernels and D2H run on three streams chained by per-slot events, so the copies of
+    // one request overlap the kernel of another (MI355X has separate SDMA engines per direction)
+    hipStream_t stream = nullptr;       // compute
+    hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<void*> dev_allocs;
     bk_net_params net[2]{};
     Slot slots[BK_MAX_INFLIGHT];
@@ -201,6 +206,8 @@ int alloc_slot(bk_engine* e, Slot& s) {
     }
     HIP_TRY(e, hipMalloc((void**)&s.d_flag, sizeof(unsigned int)));
     HIP_TRY(e, hipHostMalloc((void**)&s.h_flag, sizeof(unsigned int), hipHostMallocDefault));
+    HIP_TRY(e, hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     return BK_OK;
 }
@@ -216,6 +223,8 @@ void free_slot(Slot& s) {
     if (s.d_values) (void)hipFree(s.d_values);
     if (s.d_flag) (void)hipFree(s.d_flag);
     if (s.h_flag) (void)hipHostFree(s.h_flag);
+    if (s.in_ready) (void)hipEventDestroy(s.in_ready);
+    if (s.computed) (void)hipEventDestroy(s.computed);
     if (s.done) (void)hipEventDestroy(s.done);
     s = Slot{};
 }
@@ -352,6 +361,8 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
         return bail(BK_ERR_NO_GPU);
     }
     TRY_CREATE(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    TRY_CREATE(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    TRY_CREATE(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
 
     if (policy) {
         if ((rc = setup_trunk(e, policy->trunk, e->net[0], 1.0, 0.0))) return bail(rc);
@@ -396,14 +407,16 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
 int bk_engine_destroy(bk_engine* e) {
     if (!e) return BK_ERR_ARG;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipStream_t st : {e->s_in, e->stream, e->s_out})
+        if (st) (void)hipStreamSynchronize(st);
     for (auto& s : e->slots) free_slot(s);
     for (auto& p : e->ev_ring) {
         if (p.first) (void)hipEventDestroy(p.first);
         if (p.second) (void)hipEventDestroy(p.second);
     }
     for (void* d : e->dev_allocs) (void)hipFree(d);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (hipStream_t st : {e->s_in, e->stream, e->s_out})
+        if (st) (void)hipStreamDestroy(st);
     delete e;
     return BK_OK;
 }
@@ -424,22 +437,26 @@ int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B
     const size_t esz = feats_dtype == BK_FEATS_U8 ? 1 : 4;
     if (B > 0) {
         std::memcpy(s->h_in, feats, (size_t)B * 2187 * esz);
-        HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->s_in));
+        HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
         *s->h_flag = 0;
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
         if (e->precision == BK_PRECISION_F16X2) HIP_TRY(e, hipMemsetAsync(s->d_flag, 0, sizeof(unsigned int), e->stream));
         rc = enqueue(e, s->d_in, feats_dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
                      e->precision, s->d_flag);
         if (rc) return rc;
+        HIP_TRY(e, hipEventRecord(s->computed, e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->s_out, s->computed, 0));
         if (e->precision == BK_PRECISION_F16X2)
-            HIP_TRY(e, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, e->s_out));
         if ((want & BK_WANT_LOGITS) && n_policy)
-            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->s_out));
         if ((want & BK_WANT_PROBS) && n_policy)
-            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->s_out));
         if (want & BK_WANT_VALUE)
-            HIP_TRY(e, hipMemcpyAsync(s->h_values, s->d_values, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(s->h_values, s->d_values, (size_t)B * 4, hipMemcpyDeviceToHost, e->s_out));
     }
-    HIP_TRY(e, hipEventRecord(s->done, e->stream));
+    HIP_TRY(e, hipEventRecord(s->done, e->s_out));
     s->busy = true;
     s->ticket = e->next_ticket++;
     s->B = B;
@@ -537,7 +554,7 @@ int bk_engine_set_profiling(bk_engine* e, int on) {
 int bk_engine_synchronize(bk_engine* e) {
     if (!e) return BK_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (hipStream_t st : {e->s_in, e->stream, e->s_out}) HIP_TRY(e, hipStreamSynchronize(st));
     return BK_OK;
 }
 
