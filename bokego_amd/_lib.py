@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 1
+BK_ABI_VERSION = 2
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -44,7 +44,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("evals", ctypes.c_uint64), ("batches", ctypes.c_uint64), ("max_batch_seen", ctypes.c_uint64),
                 ("kernel_ms_sum", ctypes.c_double), ("kernel_ms_count", ctypes.c_uint64),
                 ("last_kernel_ms", ctypes.c_double), ("f16_overflow_fallbacks", ctypes.c_uint64),
-                ("f16_device_overflow", ctypes.c_uint64)]
+                ("f16_device_overflow", ctypes.c_uint64), ("positions_encoded", ctypes.c_uint64)]
 
 
 # every symbol include/bokego_amd.h declares: (restype, argtypes)
@@ -63,6 +63,8 @@ SYMBOLS = {
     "bk_submit_prefix": (ctypes.c_int64, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "bk_eval_device_prefix": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P,
                                              _P, _P]),
+    "bk_submit_positions": (ctypes.c_int64, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
+    "bk_encode_positions": (ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     "bk_engine_set_precision": (ctypes.c_int, [_P, ctypes.c_int]),
     "bk_engine_get_precision": (ctypes.c_int, [_P]),
     "bk_engine_set_profiling": (ctypes.c_int, [_P, ctypes.c_int]),

@@ -32,6 +32,7 @@ struct Slot {  // one in-flight host-buffer request
     void* h_in = nullptr;                                          // pinned staging
     float *h_logits = nullptr, *h_probs = nullptr, *h_values = nullptr;
     void* d_in = nullptr;
+    void* d_pos = nullptr;  // position records (bk_submit_positions): encoded into d_in on the GPU
     float *d_logits = nullptr, *d_probs = nullptr, *d_values = nullptr;
     unsigned int* d_flag = nullptr;  // f16x2 overflow flag of this request
     unsigned int* h_flag = nullptr;
@@ -194,6 +195,7 @@ int alloc_slot(bk_engine* e, Slot& s) {
     const size_t B = (size_t)e->max_batch;
     HIP_TRY(e, hipHostMalloc(&s.h_in, B * 2187 * sizeof(float), hipHostMallocDefault));
     HIP_TRY(e, hipMalloc(&s.d_in, B * 2187 * sizeof(float)));
+    HIP_TRY(e, hipMalloc(&s.d_pos, B * BK_POS_BYTES));
     if (e->has_policy) {
         HIP_TRY(e, hipHostMalloc((void**)&s.h_logits, B * 81 * sizeof(float), hipHostMallocDefault));
         HIP_TRY(e, hipHostMalloc((void**)&s.h_probs, B * 81 * sizeof(float), hipHostMallocDefault));
@@ -218,6 +220,7 @@ void free_slot(Slot& s) {
     if (s.h_probs) (void)hipHostFree(s.h_probs);
     if (s.h_values) (void)hipHostFree(s.h_values);
     if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_pos) (void)hipFree(s.d_pos);
     if (s.d_logits) (void)hipFree(s.d_logits);
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_values) (void)hipFree(s.d_values);
@@ -421,12 +424,16 @@ int bk_engine_destroy(bk_engine* e) {
     return BK_OK;
 }
 
-int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B, int n_policy, int want,
-                         float* logits, float* probs, float* values) {
+namespace {
+
+constexpr int kSrcPositions = 2;  // beside BK_FEATS_F32 (0) / BK_FEATS_U8 (1)
+
+// common body of the ticket entry points; src_kind: BK_FEATS_F32, BK_FEATS_U8 or kSrcPositions
+int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_policy, int want, float* logits,
+                      float* probs, float* values) {
     int rc = check_want(e, B, n_policy, want);
     if (rc) return rc;
-    if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
-    if (B > 0 && !feats) return fail(e, BK_ERR_ARG, "feats is NULL");
+    if (B > 0 && !src) return fail(e, BK_ERR_ARG, src_kind == kSrcPositions ? "positions is NULL" : "feats is NULL");
     if (((want & BK_WANT_LOGITS) && !logits) || ((want & BK_WANT_PROBS) && !probs) || ((want & BK_WANT_VALUE) && !values))
         return fail(e, BK_ERR_ARG, "an output requested in `want` has a NULL buffer");
     Slot* s = nullptr;
@@ -434,15 +441,20 @@ int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B
         if (!c.busy) { s = &c; break; }
     if (!s) return fail(e, BK_ERR_ARG, "more than BK_MAX_INFLIGHT tickets outstanding");
     HIP_TRY(e, hipSetDevice(e->device));
-    const size_t esz = feats_dtype == BK_FEATS_U8 ? 1 : 4;
+    const size_t bytes = (size_t)B * (src_kind == kSrcPositions ? (size_t)BK_POS_BYTES : src_kind == BK_FEATS_U8 ? 2187 : 2187 * 4);
+    const int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
     if (B > 0) {
-        std::memcpy(s->h_in, feats, (size_t)B * 2187 * esz);
-        HIP_TRY(e, hipMemcpyAsync(s->d_in, s->h_in, (size_t)B * 2187 * esz, hipMemcpyHostToDevice, e->s_in));
+        std::memcpy(s->h_in, src, bytes);
+        HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, e->s_in));
         HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
         *s->h_flag = 0;
         HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
+        if (src_kind == kSrcPositions) {
+            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->stream));
+            e->st.positions_encoded += (uint64_t)B;
+        }
         if (e->precision == BK_PRECISION_F16X2) HIP_TRY(e, hipMemsetAsync(s->d_flag, 0, sizeof(unsigned int), e->stream));
-        rc = enqueue(e, s->d_in, feats_dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
+        rc = enqueue(e, s->d_in, dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
                      e->precision, s->d_flag);
         if (rc) return rc;
         HIP_TRY(e, hipEventRecord(s->computed, e->stream));
@@ -461,12 +473,50 @@ int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B
     s->ticket = e->next_ticket++;
     s->B = B;
     s->n_policy = n_policy;
-    s->dtype = feats_dtype;
+    s->dtype = dtype;
     s->want = want;
     s->logits = logits;
     s->probs = probs;
     s->values = values;
     return s->ticket;
+}
+
+}  // namespace
+
+int64_t bk_submit_prefix(bk_engine* e, const void* feats, int feats_dtype, int B, int n_policy, int want,
+                         float* logits, float* probs, float* values) {
+    if (!e) return BK_ERR_ARG;
+    if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");
+    return submit_common(e, feats, feats_dtype, B, n_policy, want, logits, probs, values);
+}
+
+int64_t bk_submit_positions(bk_engine* e, const void* positions, int B, int n_policy, int want, float* logits,
+                            float* probs, float* values) {
+    if (!e) return BK_ERR_ARG;
+    return submit_common(e, positions, kSrcPositions, B, n_policy, want, logits, probs, values);
+}
+
+int bk_encode_positions(bk_engine* e, const void* positions, int B, uint8_t* planes) {
+    if (!e) return BK_ERR_ARG;
+    if (B < 0) return fail(e, BK_ERR_ARG, "bad B");
+    if (B > e->max_batch) return fail(e, BK_ERR_BATCH, "B exceeds max_batch given at bk_engine_create");
+    if (B == 0) return BK_OK;
+    if (!positions || !planes) return fail(e, BK_ERR_ARG, "positions or planes is NULL");
+    Slot* s = nullptr;
+    for (auto& c : e->slots)
+        if (!c.busy) { s = &c; break; }
+    if (!s) return fail(e, BK_ERR_ARG, "more than BK_MAX_INFLIGHT tickets outstanding");
+    HIP_TRY(e, hipSetDevice(e->device));
+    // pinned staging: records at the front of h_in, the planes behind them (h_in holds B x 8,748 bytes)
+    uint8_t* h_planes = static_cast<uint8_t*>(s->h_in) + (((size_t)B * BK_POS_BYTES + 255) & ~(size_t)255);
+    std::memcpy(s->h_in, positions, (size_t)B * BK_POS_BYTES);
+    HIP_TRY(e, hipMemcpyAsync(s->d_pos, s->h_in, (size_t)B * BK_POS_BYTES, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->stream));
+    HIP_TRY(e, hipMemcpyAsync(h_planes, s->d_in, (size_t)B * 2187, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    std::memcpy(planes, h_planes, (size_t)B * 2187);
+    e->st.positions_encoded += (uint64_t)B;
+    return BK_OK;
 }
 
 int bk_wait(bk_engine* e, int64_t ticket) {

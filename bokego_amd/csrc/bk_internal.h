@@ -54,6 +54,11 @@ struct bk_eval_args {
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
+#define BK_POS_BYTES 192  // sizeof(bk_pos), include/bokego_go.h
+
+// feature planes [B][27][9][9] u8 from B position records (bk_encode.hip)
+hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream);
+
 int bk_pick_nb(int B_policy, int B_value, int n_cu);
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -371,7 +371,15 @@ bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t
 
 void bk_pool_destroy(bk_pool* p) { delete p; }
 
-int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
+}  // extern "C"
+
+namespace {
+
+// advance every game to its next evaluation request and lay the batch out:
+// [policy nodes of every game ...][value nodes of every game ...]; games whose request does not fit under
+// `cap` keep it for the next collect.  emit(node position, row) writes one row of the batch.
+template <typename Emit>
+int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     const int G = (int)p->games.size();
     std::vector<char> wants(G, 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
@@ -380,8 +388,6 @@ int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
         if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
         else if (gm.has_request()) wants[g] = 1;
     }
-    // batch layout: [policy nodes of every game ...][value nodes of every game ...]; games whose
-    // request does not fit under `cap` keep it for the next collect
     p->active.clear();
     p->pol_off.clear();
     p->val_off.clear();
@@ -401,14 +407,31 @@ int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
     for (int a = 0; a < A; ++a) {
         Game& gm = p->games[p->active[a]];
-        for (size_t i = 0; i < gm.req_policy.size(); ++i)
-            bk_pos_features_u8(&gm.nodes[gm.req_policy[i]].pos, feats + (size_t)(p->pol_off[a] + i) * 2187, 0);
-        for (size_t i = 0; i < gm.req_value.size(); ++i)
-            bk_pos_features_u8(&gm.nodes[gm.req_value[i]].pos, feats + (size_t)(npol + p->val_off[a] + i) * 2187, 0);
+        for (size_t i = 0; i < gm.req_policy.size(); ++i) emit(&gm.nodes[gm.req_policy[i]].pos, (size_t)(p->pol_off[a] + i));
+        for (size_t i = 0; i < gm.req_value.size(); ++i) emit(&gm.nodes[gm.req_value[i]].pos, (size_t)(npol + p->val_off[a] + i));
         gm.n_requests += 1;
     }
     *n_policy = npol;
     return npol + nval;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
+    return collect_impl(p, cap, n_policy, [feats](bk_pos* pos, size_t row) { bk_pos_features_u8(pos, feats + row * 2187, 0); });
+}
+
+int bk_pool_collect_pos(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
+    // the history-dependent half of nnet.features() -- the lazy liberty-cache refresh, go.py:220-243 -- runs
+    // here, on the node itself (its children inherit the refreshed cache, as with bk_pool_collect); the
+    // planes are then a pure function of the record and are computed by the consumer (the GPU encoder)
+    return collect_impl(p, cap, n_policy, [out](bk_pos* pos, size_t row) {
+        uint8_t libs[81];
+        bk_pos_liberties(pos, libs);
+        out[row] = *pos;
+    });
 }
 
 void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {

@@ -160,6 +160,47 @@ class LeafEngine:
         self._pending[t] = (a, out)
         return t
 
+    @staticmethod
+    def _records(positions):
+        """positions: np.uint8 [B,192] (bk_pos records) or a ctypes array of go.Pos."""
+        if isinstance(positions, np.ndarray):
+            a = np.ascontiguousarray(positions, np.uint8)
+            if a.ndim != 2 or a.shape[1] != 192:
+                raise ValueError(f"position records must have shape [B,192], got {a.shape}")
+            return a
+        import ctypes
+        n = ctypes.sizeof(positions)
+        if n % 192:
+            raise ValueError("position records must be 192 bytes each")
+        return np.frombuffer(positions, np.uint8).reshape(-1, 192)
+
+    def submit_positions(self, positions, logits=False, probs=True, value=True, n_policy=None):
+        """As submit(), from position records (go.Pos / bk_pos, liberty cache refreshed by the host): the GPU
+        encodes the 27 planes itself.  Same results as submit(features_u8) bit for bit."""
+        a = self._records(positions)
+        B = a.shape[0]
+        npol = B if n_policy is None else int(n_policy)
+        want = self._want(logits, probs, value)
+        out = {}
+        if logits:
+            out["logits"] = np.empty((npol, 81), np.float32)
+        if probs:
+            out["probs"] = np.empty((npol, 81), np.float32)
+        if value:
+            out["value"] = np.empty((B,), np.float32)
+        p = lambda k: out[k].ctypes.data if k in out else None  # noqa: E731
+        t = self._check(self._lib.bk_submit_positions(self._h, a.ctypes.data, B, npol, want, p("logits"), p("probs"),
+                                                      p("value")))
+        self._pending[t] = (a, out)
+        return t
+
+    def encode_positions(self, positions):
+        """The GPU encoder alone: uint8 [B,27,9,9] planes of the given position records."""
+        a = self._records(positions)
+        out = np.empty((a.shape[0], 27, 9, 9), np.uint8)
+        self._check(self._lib.bk_encode_positions(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
     def wait(self, ticket):
         a, out = self._pending.pop(ticket)
         self._check(self._lib.bk_wait(self._h, ticket))

@@ -92,7 +92,10 @@ class NativeMCTS:
     def _pump(self):
         """Run the native search until it needs nothing more (every outstanding rollout done)."""
         while True:
-            feats, npol = self._pool.collect()
+            if getattr(self.evaluator, "wants_positions", False):
+                feats, npol = self._pool.collect_positions()   # planes are encoded on the GPU
+            else:
+                feats, npol = self._pool.collect()
             if len(feats) == 0:
                 return
             self._pool.deliver(*self.evaluator(feats, npol))

@@ -45,6 +45,7 @@ TREE_SYMBOLS = {
     "bk_pool_create": (_VP, [ctypes.c_int, ctypes.POINTER(SearchParams), _VP, ctypes.c_int]),
     "bk_pool_destroy": (None, [_VP]),
     "bk_pool_collect": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "bk_pool_collect_pos": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
     "bk_pool_n_games": (ctypes.c_int, [_VP]),
     "bk_pool_n_done": (ctypes.c_int, [_VP]),
@@ -95,7 +96,7 @@ class GamePool:
         self._h = self._lib.bk_pool_create(self.n, ctypes.byref(params), self.seeds.ctypes.data, int(threads))
         if not self._h:
             raise RuntimeError("bk_pool_create failed")
-        self._feats = np.empty((self.cap, 27, 9, 9), np.uint8)
+        self._feats = self._recs = None   # allocated by the collect flavour in use
 
     def close(self):
         if self._h:
@@ -107,9 +108,20 @@ class GamePool:
 
     def collect(self):
         """-> (uint8 feats [B,27,9,9] view, n_policy); B == 0 when every game is finished."""
+        if self._feats is None:
+            self._feats = np.empty((self.cap, 27, 9, 9), np.uint8)
         npol = ctypes.c_int(0)
         B = self._lib.bk_pool_collect(self._h, self._feats.ctypes.data, self.cap, ctypes.byref(npol))
         return self._feats[:B], npol.value
+
+    def collect_positions(self):
+        """-> (uint8 records [B,192] view, n_policy): the same batch as collect(), as position records whose
+        planes the consumer computes (LeafEngine.submit_positions encodes them on the GPU)."""
+        if self._recs is None:
+            self._recs = np.empty((self.cap, 192), np.uint8)
+        npol = ctypes.c_int(0)
+        B = self._lib.bk_pool_collect_pos(self._h, self._recs.ctypes.data, self.cap, ctypes.byref(npol))
+        return self._recs[:B], npol.value
 
     def deliver(self, probs, values):
         probs = np.ascontiguousarray(probs, dtype=np.float32)
@@ -152,15 +164,20 @@ def normalise_like_categorical(probs):
 
 
 class EngineEvaluator:
-    """feats -> (probs, values) on a LeafEngine, synchronous or split into submit/finish."""
+    """feats (or position records) -> (probs, values) on a LeafEngine, synchronous or split into submit/finish.
+    gpu_encode=True (default): drivers hand over 192-byte position records (GamePool.collect_positions) and
+    the engine computes the 27 planes on the GPU; False: host-encoded uint8 planes (GamePool.collect)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, gpu_encode=True):
         self.engine = engine
+        self.wants_positions = bool(gpu_encode)
         self.positions = self.batches = 0
 
     def submit(self, feats, n_policy):
         self.positions += len(feats)
         self.batches += 1
+        if feats.ndim == 2:   # [B,192] position records
+            return self.engine.submit_positions(feats, logits=False, probs=n_policy > 0, value=True, n_policy=n_policy), n_policy
         return self.engine.submit(feats, logits=False, probs=n_policy > 0, value=True, n_policy=n_policy), n_policy
 
     def finish(self, handle):
@@ -213,7 +230,7 @@ def run_pools(pools, evaluator, progress=None):
                 pool.deliver(probs, values)
                 inflight[i] = None
             if live[i]:
-                feats, npol = pool.collect()
+                feats, npol = pool.collect_positions() if getattr(evaluator, "wants_positions", False) else pool.collect()
                 if len(feats) == 0:
                     live[i] = False
                 else:
@@ -268,7 +285,7 @@ def shard_game_ids(n_games, rank, world):
 
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
-              sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=2,
+              sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=3,
               reduce_device=None, progress=None, prune=1, record_visits=0):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict)."""
     gids = shard_game_ids(n_games, rank, world)
@@ -390,7 +407,8 @@ def main():
     ap.add_argument("--value", default=None)
     ap.add_argument("--max-batch", type=int, default=8192)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--pools", type=int, default=2, help="lock-step pools per rank (host/GPU overlap)")
+    ap.add_argument("--pools", type=int, default=3, help="lock-step pools per rank (host/GPU overlap)")
+    ap.add_argument("--host-encode", action="store_true", help="encode the 27 planes on the host instead of on the GPU")
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     args = ap.parse_args()
 
@@ -415,7 +433,7 @@ def main():
 
     eng = LeafEngine(load(args.policy, "policy_19.bkw"), load(args.value, "value_synth.bkw"), device_id=local_rank,
                      max_batch=args.max_batch)
-    ev = EngineEvaluator(eng)
+    ev = EngineEvaluator(eng, gpu_encode=not args.host_encode)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
                              reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)))

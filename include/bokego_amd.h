@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 1
+#define BK_ABI_VERSION 2
 
 typedef enum bk_status {
     BK_OK = 0,
@@ -88,6 +88,7 @@ typedef struct bk_stats_t {
     double last_kernel_ms;
     uint64_t f16_overflow_fallbacks; /* host-buffer requests redone in fp32 because an activation left the fp16 range */
     uint64_t f16_device_overflow;    /* bk_eval_device*: non-zero if that ever happened (results of that call unreliable) */
+    uint64_t positions_encoded;      /* position records turned into feature planes on the GPU */
 } bk_stats_t;
 
 int bk_abi_version(void);
@@ -139,6 +140,21 @@ int64_t bk_submit_prefix(bk_engine *e, const void *feats, int feats_dtype, int B
                          float *logits, float *probs, float *values);
 int bk_eval_device_prefix(bk_engine *e, const void *d_feats, int feats_dtype, int B, int n_policy, int want,
                           float *d_logits, float *d_probs, float *d_values, void *stream);
+
+/*
+ * Position records in, instead of feature planes ("optional HIP encoder writing uint8 planes
+ * straight into the engine's input buffer").  `positions` is an array of B 192-byte bk_pos records
+ * (include/bokego_go.h) whose liberty cache has been refreshed by the host (bk_pos_liberties /
+ * bk_pool_collect_pos -- the history-dependent part of nnet.features(), nnet.py:213-215, go.py:220-243,
+ * stays on the host); the GPU computes the 27 planes of nnet.py:216-262 from each record and evaluates
+ * them.  Results are bit-identical to bk_submit_prefix(bk_pos_features_u8(...)); 192 B instead of 2,187 B
+ * cross PCIe per leaf and the host spends no time encoding.
+ */
+#define BK_POS_RECORD_BYTES 192
+int64_t bk_submit_positions(bk_engine *e, const void *positions, int B, int n_policy, int want, float *logits,
+                            float *probs, float *values);
+/* the encoder alone: planes[B][27][9][9] uint8 on the host (tests, diagnostics); synchronous */
+int bk_encode_positions(bk_engine *e, const void *positions, int B, uint8_t *planes);
 
 /*
  * Arithmetic of the conv stacks (new; the reference computes in torch fp32):

@@ -63,6 +63,11 @@ void bk_pool_destroy(bk_pool *p);
  * feature planes (uint8 [B][27][9][9]) to feats: first the n_policy positions that need policy
  * (+value), then the value-only ones.  Returns B (0 when every game is over).  cap >= 82. */
 int bk_pool_collect(bk_pool *p, uint8_t *feats, int cap, int *n_policy);
+/* Same batch, as 192-byte position records instead of planes: each requested node's liberty cache is
+ * refreshed in place (the history-dependent half of nnet.features(), go.py:220-243) and the record copied
+ * to out[B]; the planes are a pure function of the record (bk_pos_features_u8 on it gives exactly what
+ * bk_pool_collect would have written) and are computed on the GPU by bk_submit_positions. */
+int bk_pool_collect_pos(bk_pool *p, bk_pos *out, int cap, int *n_policy);
 /* probs: [n_policy][81] (already Categorical-normalised), values: [B], same order as collected */
 void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 

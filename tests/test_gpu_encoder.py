@@ -1,0 +1,110 @@
+"""The GPU feature encoder (bk_encode.hip behind bk_encode_positions / bk_submit_positions) against the
+reference's planes (tests/golden/features.npz, recorded from nnet.features()) and against the host encoder."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (binds the HIP runtime before the engine library loads)
+
+from bokego_amd import go, selfplay, workload
+from bokego_amd.bkw import load_bkw
+from bokego_amd.engine import LeafEngine
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")),
+                      max_batch=4096)
+
+
+def _record(g):
+    """The 192-byte record the host hands to the GPU: liberty cache refreshed exactly as features() would."""
+    g.get_liberties()
+    return np.frombuffer(bytes(g._pos), np.uint8).copy()
+
+
+def _golden_records():
+    pos = json.load(open(os.path.join(GOLDEN, "positions.json")))
+    recs, fresh_recs = [], []
+    games = [pos["sgf_moves"][f"boke_gnugo_{i}"] for i in range(1, 11)]
+    starts_with_empty = []
+    i = 0
+    order = []
+    for moves in games:
+        order.append((moves, i))
+        i += len(moves) + (1 if pos["positions"][i]["turn"] == 0 else 0)
+    for name, (lo, hi) in pos["handmade_index"].items():
+        order.append((pos["handmade_moves"][name], lo))
+    idx = []
+    for moves, start in order:
+        g = go.Game(moves=[])
+        k = start
+        if pos["positions"][k]["turn"] == 0:
+            recs.append(_record(g)); idx.append(k); k += 1
+        for m in moves:
+            g.play_move(m)
+            recs.append(_record(g)); idx.append(k)
+            r = pos["positions"][k]
+            h = go.Game(board=r["board"], ko=r["ko"], last_move=r["last_move"], turn=r["turn"])
+            fresh_recs.append((k, _record(h)))
+            k += 1
+    return np.stack(recs), np.array(idx), fresh_recs
+
+
+def test_gpu_planes_equal_reference_goldens(eng):
+    f = np.load(os.path.join(GOLDEN, "features.npz"))
+    finc, ffresh = f["incremental"].astype(np.uint8), f["fresh"].astype(np.uint8)
+    recs, idx, fresh_recs = _golden_records()
+    assert len(recs) == len(finc) == 536 and sorted(idx.tolist()) == list(range(536))
+    planes = eng.encode_positions(recs)
+    assert np.array_equal(planes, finc[idx])               # incremental (history-dependent liberty cache) mode
+    fr = np.stack([r for _, r in fresh_recs])
+    planes = eng.encode_positions(fr)
+    assert np.array_equal(planes, ffresh[[k for k, _ in fresh_recs]])   # positions built from a board string
+    assert eng.stats()["positions_encoded"] == len(recs) + len(fr)
+
+
+def test_gpu_planes_equal_host_encoder_on_playouts(eng):
+    recs, host = [], []
+    for s in range(600):
+        g, _ = workload.random_playout(50_000 + s, max_len=80)
+        recs.append(_record(g))
+        host.append(g.features_u8())
+    recs, host = np.stack(recs), np.stack(host)
+    for lo, hi in ((0, 600), (0, 1), (3, 5), (10, 17)):      # full blocks, partial blocks, a single position
+        assert np.array_equal(eng.encode_positions(recs[lo:hi]), host[lo:hi])
+    assert eng.encode_positions(recs[:0]).shape == (0, 27, 9, 9)
+
+
+def test_submit_positions_bit_identical_to_submit_features(eng):
+    recs, host = [], []
+    for s in range(300):
+        g, _ = workload.random_playout(70_000 + s)
+        recs.append(_record(g))
+        host.append(g.features_u8())
+    recs, host = np.stack(recs), np.stack(host)
+    for npol in (300, 7, 0):
+        a = eng.wait(eng.submit_positions(recs, logits=npol > 0, probs=npol > 0, value=True, n_policy=npol))
+        b = eng.wait(eng.submit(host, logits=npol > 0, probs=npol > 0, value=True, n_policy=npol))
+        for k in b:
+            assert np.array_equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        eng.submit_positions(np.zeros((4, 100), np.uint8))
+    with pytest.raises(ValueError):
+        eng.encode_positions(np.zeros((5000, 192), np.uint8))   # > max_batch
+
+
+def test_self_play_same_games_with_gpu_and_host_encoding(eng):
+    res = []
+    for gpu_encode in (True, False):
+        ev = selfplay.EngineEvaluator(eng, gpu_encode=gpu_encode)
+        local, total = selfplay.self_play(ev, n_games=24, rollouts=60, expand_thresh=20, max_turns=40, cap=4096)
+        res.append((local["games"], total))
+    assert res[0][0] == res[1][0]
+    assert res[0][1] == res[1][1]

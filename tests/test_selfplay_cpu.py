@@ -188,3 +188,33 @@ def test_policy_playouts_reference_surface_and_records(tmp_path):
     assert set(rec) == {"0", "1", "2"} and len(rec["0"]["visits"]) == len(rec["0"]["moves"]) == 6
     assert sum(rec["0"]["visits"][0].values()) == 20
     assert go.get_moves(str(tmp_path / "game_00000.sgf")) == rec["0"]["moves"]
+
+
+def test_collect_positions_equals_collect_features():
+    """bk_pool_collect_pos hands out records whose host-encoded planes are exactly what bk_pool_collect writes
+    (the GPU encoder is checked against the same host encoder in tests/test_gpu_mcts.py)."""
+    import ctypes
+    from bokego_amd import go
+    prm = selfplay.search_params(rollouts=40, expand_thresh=10, noise_weight=0.25, sample_plies=4, max_turns=30, prune=1)
+    a = selfplay.GamePool([7, 8, 9, 10], prm, cap=512, threads=2)
+    b = selfplay.GamePool([7, 8, 9, 10], prm, cap=512, threads=2)
+    rng = np.random.default_rng(0)
+    lib = go.golib()
+    steps = 0
+    while True:
+        fa, na = a.collect()
+        rb, nb = b.collect_positions()
+        assert len(fa) == len(rb) and na == nb
+        if len(fa) == 0:
+            break
+        recs = rb.copy()
+        planes = np.empty((len(recs), 27, 9, 9), np.uint8)
+        lib.bk_features_batch_u8(recs.ctypes.data, len(recs), 192, planes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 0)
+        assert np.array_equal(planes, fa)
+        probs = rng.random((na, 81), dtype=np.float32)
+        probs /= probs.sum(1, keepdims=True)
+        vals = rng.random(len(fa), dtype=np.float32) - 0.5
+        a.deliver(probs, vals)
+        b.deliver(probs, vals)
+        steps += 1
+    assert steps > 20 and [a.moves(g) for g in range(4)] == [b.moves(g) for g in range(4)]
