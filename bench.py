@@ -39,7 +39,7 @@ def make_workload(B, rank):
     moves) encoded by the build's own board engine in incremental mode -> f32 [B,27,9,9].  The recipe
     is pinned move-for-move against the reference's rules engine by tests/golden/playouts.json."""
     from bokego_amd.workload import make_batch
-    return make_batch(B, seed_base=20260 + rank * B, dtype=np.float32)
+    return make_batch(B, seed_base=20260 + rank * B, dtype=np.float32, with_records=True)
 
 
 def measured_traffic(batch):
@@ -126,7 +126,7 @@ def main():
     g = os.path.join(REPO, "tests", "golden")
     pw, vw = load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw"))
     eng = LeafEngine(pw, vw, device_id=local_rank, max_batch=args.batch, precision=args.precision)
-    x_host = make_workload(args.batch, rank)
+    x_host, x_recs = make_workload(args.batch, rank)
     x = torch.from_numpy(x_host).cuda()
 
     def barrier():
@@ -168,7 +168,7 @@ def main():
     # (a) synchronous bk_eval with f32 planes, as the reference's host tensors would arrive;
     # (b) what the ABI is built for: uint8 planes, three tickets in flight (the engine runs H2D, kernels
     #     and D2H on three streams chained by events).
-    e2e = e2e_u8 = None
+    e2e = e2e_u8 = e2e_pos = None
     if rank == 0:
         eng.eval(x_host, logits=False, probs=True, value=True)
         t1 = time.perf_counter()
@@ -186,6 +186,18 @@ def main():
         while pend:
             eng.wait(pend.pop(0))
         e2e_u8 = n_e2e * args.batch / (time.perf_counter() - t1)
+        # (c) 192-byte position records in, planes encoded on the GPU (bk_submit_positions)
+        ref = eng.eval(x_u8, logits=False, probs=True, value=True)
+        got = eng.wait(eng.submit_positions(x_recs, logits=False, probs=True, value=True))
+        assert np.array_equal(ref["probs"], got["probs"]) and np.array_equal(ref["value"], got["value"])
+        t1 = time.perf_counter()
+        for _ in range(n_e2e):
+            pend.append(eng.submit_positions(x_recs, logits=False, probs=True, value=True))
+            if len(pend) == 3:
+                eng.wait(pend.pop(0))
+        while pend:
+            eng.wait(pend.pop(0))
+        e2e_pos = n_e2e * args.batch / (time.perf_counter() - t1)
 
     # Secondary measurement (outside the timed region above): BASELINE config 4 -- 512 self-play games,
     # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
@@ -251,6 +263,7 @@ def main():
             "selfplay": sp,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,
+            "host_positions_e2e_pipelined_leaf_evals_per_s": e2e_pos,
         }
         print(json.dumps(line), flush=True)
     eng.close()

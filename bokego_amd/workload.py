@@ -25,10 +25,14 @@ def random_playout(seed, max_len=60):
     return g, moves
 
 
-def make_batch(B, seed_base=20260, dtype=np.float32):
-    """[B,27,9,9] feature planes of B random-playout positions (seeds seed_base .. seed_base+B-1)."""
+def make_batch(B, seed_base=20260, dtype=np.float32, with_records=False):
+    """[B,27,9,9] feature planes of B random-playout positions (seeds seed_base .. seed_base+B-1); with
+    with_records also the same positions as uint8 [B,192] records (liberty cache refreshed), the input of
+    LeafEngine.submit_positions."""
     out = np.empty((B, 27, 9, 9), np.uint8)
+    recs = np.empty((B, 192), np.uint8)
     for i in range(B):
         g, _ = random_playout(seed_base + i)
         out[i] = g.features_u8()
-    return out.astype(dtype)
+        recs[i] = np.frombuffer(bytes(g._pos), np.uint8)   # features_u8 has refreshed the cache
+    return (out.astype(dtype), recs) if with_records else out.astype(dtype)
