@@ -285,12 +285,14 @@ def shard_game_ids(n_games, rank, world):
 
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
-              sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=3,
+              sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
               reduce_device=None, progress=None, prune=1, record_visits=0):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict)."""
     gids = shard_game_ids(n_games, rank, world)
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits)
+    if n_pools is None:   # measured: three rotating pools pay off from ~200 games per rank, two below
+        n_pools = 3 if len(gids) >= 192 else 2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     parts = [gids[i::n_pools] for i in range(n_pools)]
     pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
@@ -407,7 +409,7 @@ def main():
     ap.add_argument("--value", default=None)
     ap.add_argument("--max-batch", type=int, default=8192)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--pools", type=int, default=3, help="lock-step pools per rank (host/GPU overlap)")
+    ap.add_argument("--pools", type=int, default=None, help="lock-step pools per rank (host/GPU overlap; default 3 from 192 games per rank, else 2)")
     ap.add_argument("--host-encode", action="store_true", help="encode the 27 planes on the host instead of on the GPU")
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     args = ap.parse_args()
