@@ -10,11 +10,12 @@ from bokego_amd.engine import LeafEngine
 
 n_pools = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 gpu_encode = (sys.argv[2] if len(sys.argv) > 2 else "gpu") == "gpu"
+n_games = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw")), max_batch=4096)
 ev = selfplay.EngineEvaluator(eng, gpu_encode=gpu_encode)
 prm = selfplay.search_params(rollouts=400, expand_thresh=100, noise_weight=0.25, sample_plies=8, max_turns=80, prune=1)
-gids = list(range(512))
+gids = list(range(n_games))
 pools = [selfplay.GamePool([20260 + x for x in gids[i::n_pools]], prm, cap=4096) for i in range(n_pools)]
 T = dict(wait=0.0, deliver=0.0, collect=0.0, submit=0.0)
 inflight = [None] * n_pools
@@ -35,6 +36,6 @@ while any(live) or any(h is not None for h in inflight):
                 t = time.perf_counter(); inflight[i] = ev.submit(feats, npol); T["submit"] += time.perf_counter() - t
                 steps += 1; pos += len(feats)
 tot = time.perf_counter() - t_all
-print(f"pools {n_pools}, planes encoded on the {'GPU' if gpu_encode else 'host'}: {tot:.3f} s, {steps} steps, mean batch {pos / steps:.0f}, {512 / tot * 60:.0f} games/min")
+print(f"games {n_games}, pools {n_pools}, planes encoded on the {'GPU' if gpu_encode else 'host'}: {tot:.3f} s, {steps} steps, mean batch {pos / steps:.0f}, {n_games / tot * 60:.0f} games/min")
 for k, v in T.items():
     print(f"  {k:8s} {v:.3f} s  {100 * v / tot:5.1f} %  {v / steps * 1e3:.3f} ms/step")
