@@ -1,4 +1,4 @@
-"""LeafEngine: Python handle of one bk_engine (one HIP stream on one MI355X).
+"""LeafEngine: Python handle of one bk_engine (one consumer thread, one MI355X).
 
 Batches positions through the fused HIP kernel.  Mirrors what the reference does one
 position at a time in nnet.policy_dist / nnet.value (bokego/nnet.py:265-284).

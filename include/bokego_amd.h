@@ -11,9 +11,10 @@
  * host (or, where stated, device) pointers; no torch types cross this boundary.
  *
  * Conventions: every function returns BK_OK (0) or a negative bk_status; the message of the
- * last failure on an engine is available from bk_last_error().  One engine = one HIP stream =
- * one consumer thread (the reference calls the nets from a single thread, gtp.py:98-108);
- * several engines per process/device are allowed.
+ * last failure on an engine is available from bk_last_error().  One engine = one consumer thread
+ * (the reference calls the nets from a single thread, gtp.py:98-108) and one private set of HIP
+ * streams (copy-in, compute, copy-out, chained by events so that tickets overlap); several engines
+ * per process/device are allowed.
  */
 #ifndef BOKEGO_AMD_H
 #define BOKEGO_AMD_H
@@ -124,7 +125,8 @@ int bk_eval_device(bk_engine *e, const void *d_feats, int feats_dtype, int B, in
 /*
  * Asynchronous host-buffer variant for the batched leaf queue: returns a ticket (>0) or a
  * negative bk_status.  Host buffers must stay alive until bk_wait(ticket) returns.  At most
- * BK_MAX_INFLIGHT tickets may be outstanding.
+ * BK_MAX_INFLIGHT tickets may be outstanding; with two or three in flight the H2D copy of one, the
+ * kernel of another and the D2H copy of a third run concurrently.
  */
 #define BK_MAX_INFLIGHT 4
 int64_t bk_submit(bk_engine *e, const void *feats, int feats_dtype, int B, int want, float *logits, float *probs,
