@@ -7,12 +7,15 @@
  * whose cache misses are exactly "enqueue a leaf".  The pool turns those misses into batches:
  *
  *   for (;;) {
- *       B = bk_pool_collect(pool, feats, cap, &n_policy);   // every game runs until it needs a network
+ *       B = bk_pool_collect_pos(pool, recs, cap, &n_policy); // every game runs until it needs a network
  *       if (B == 0) break;                                   // all games finished
- *       bk_submit_prefix(engine, feats, BK_FEATS_U8, B, n_policy, PROBS|VALUE, NULL, probs, values);
+ *       t = bk_submit_positions(engine, recs, B, n_policy, PROBS|VALUE, NULL, probs, values);   // planes made on the GPU
+ *       bk_wait(engine, t);
  *       ... renormalise probs rows as torch's Categorical does (nnet.py:274) ...
  *       bk_pool_deliver(pool, probs, values);
  *   }
+ * (bk_pool_collect + bk_submit_prefix is the same loop with the planes encoded on the host.)  Several pools
+ * rotate through one engine so that the host advances one while the GPU evaluates the others.
  */
 #ifndef BOKEGO_TREE_H
 #define BOKEGO_TREE_H
