@@ -7,7 +7,9 @@
 // the host (bk_pos_liberties / bk_pool_collect_pos run it before the record is copied); everything else is a
 // pure function of (board, libs, ko, last_move, turn) and is computed here.
 //
-// Mapping: one workgroup = 3 positions x 81 points (243 of 256 threads), one thread per board point.
+// Mapping: one workgroup = one position, 128 threads, one thread per board point (81 active).  The workgroup
+// needs 2.8 KB of LDS and few registers on purpose: it is launched on the engine's copy-in stream, so it runs
+// *under* the previous request's leaf kernel, whose 3-board workgroups leave 4.6 KB of LDS per CU free.
 //   1. chains by label propagation in LDS (label = smallest point index of the chain, min over same-colour
 //      neighbours + pointer jumping, until no label changes);
 //   2. per chain: stone mask, neighbour mask (96-bit, three LDS words) and size, by LDS atomics;
@@ -21,13 +23,16 @@
 namespace {
 
 constexpr int NN = 81;
-constexpr int PB = 3;  // positions per workgroup
 
 struct Mask {
     unsigned w[3];
 };
 
-__device__ __forceinline__ void mask_set(Mask& m, int s) { m.w[s >> 5] |= 1u << (s & 31); }
+__device__ __forceinline__ void mask_set(Mask& m, int s) {  // no dynamic register indexing
+    const unsigned bit = 1u << (s & 31);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m.w[i] |= (s >> 5) == i ? bit : 0u;
+}
 __device__ __forceinline__ int mask_pop(const Mask& m) { return __popc(m.w[0]) + __popc(m.w[1]) + __popc(m.w[2]); }
 
 struct PosLds {
@@ -41,26 +46,22 @@ struct PosLds {
     int ko, last_move, turn;
 };
 
-__global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __restrict__ pos, int B,
+__global__ void __launch_bounds__(128) bk_encode_kernel(const unsigned char* __restrict__ pos, int B,
                                                        unsigned char* __restrict__ planes) {
-    __shared__ PosLds L[PB];
-    const int tid = threadIdx.x;
-    const int pl = tid / NN;            // position slot of this thread (3 = idle lanes 243..255)
-    const int q = tid - pl * NN;        // board point
-    const int b = blockIdx.x * PB + pl;
-    const bool live = pl < PB && b < B;
+    __shared__ PosLds P;
+    const int q = threadIdx.x;          // board point (lanes 81..127 idle, they only take part in the barriers)
+    const int b = blockIdx.x;
+    const bool live = q < NN && b < B;
     const int r = q / 9, c = q - 9 * r;
 
-    // neighbours (go.py:375-383 order is irrelevant here: only sums / unions are formed)
-    int nb[4], nn = 0;
-    if (r + 1 < 9) nb[nn++] = q + 9;
-    if (r - 1 >= 0) nb[nn++] = q - 9;
-    if (c + 1 < 9) nb[nn++] = q + 1;
-    if (c - 1 >= 0) nb[nn++] = q - 1;
+    // neighbours (go.py:375-383 order is irrelevant here: only sums / unions are formed); fixed slots with a
+    // validity mask so that nothing is indexed dynamically
+    const int nb[4] = {q + 9, q - 9, q + 1, q - 1};
+    const bool nv[4] = {r + 1 < 9, r >= 1, c + 1 < 9, c >= 1};
+    constexpr int nn = 4;
 
     int me_board = 0, my_libs = 0;
     if (live) {
-        PosLds& P = L[pl];
         const unsigned char* src = pos + (size_t)b * 192;
         me_board = (signed char)src[q];
         my_libs = src[81 + q];
@@ -83,10 +84,10 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
     for (;;) {
         int changed = 0;
         if (live && me_board) {
-            PosLds& P = L[pl];
             int m = P.label[q];
+#pragma unroll
             for (int k = 0; k < nn; ++k)
-                if (P.board[nb[k]] == me_board) m = min(m, P.label[nb[k]]);
+                if (nv[k] && P.board[nb[k]] == me_board) m = min(m, P.label[nb[k]]);
             m = min(m, P.label[m]);  // pointer jumping: labels only ever point to smaller indices of the same chain
             if (m < P.label[q]) { P.label[q] = m; changed = 1; }
         }
@@ -96,11 +97,12 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
 
     // ---- 2. per-chain masks ----
     if (live) {
-        PosLds& P = L[pl];
         if (me_board) {
             const int g = P.label[q];
             atomicOr(&P.stones[g][q >> 5], 1u << (q & 31));
-            for (int k = 0; k < nn; ++k) atomicOr(&P.nbrs[g][nb[k] >> 5], 1u << (nb[k] & 31));
+#pragma unroll
+            for (int k = 0; k < nn; ++k)
+                if (nv[k]) atomicOr(&P.nbrs[g][nb[k] >> 5], 1u << (nb[k] & 31));
             atomicAdd(&P.size[g], 1);
         } else {
             atomicOr(&P.empty[q >> 5], 1u << (q & 31));
@@ -110,7 +112,6 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
 
     // ---- 3/4. planes ----
     if (!live) return;
-    const PosLds& P = L[pl];
     unsigned char* out = planes + (size_t)b * 2187 + q;
     const int me = (P.turn & 1) ? 2 : 1, opp = 3 - me;
     unsigned char v[27];
@@ -126,11 +127,15 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
     bool legal = false;
     if (me_board == 0 && q != P.ko) {
         Mask nbm{{0, 0, 0}}, lib{{0, 0, 0}}, cap{{0, 0, 0}};
-        for (int k = 0; k < nn; ++k) mask_set(nbm, nb[k]);
+#pragma unroll
+        for (int k = 0; k < nn; ++k)
+            if (nv[k]) mask_set(nbm, nb[k]);
         for (int i = 0; i < 3; ++i) lib.w[i] = nbm.w[i] & P.empty[i];
         Mask chain_nbrs = nbm;
         int cap_dup = 0;
+#pragma unroll
         for (int k = 0; k < nn; ++k) {
+            if (!nv[k]) continue;
             const int t = nb[k], bt = P.board[t];
             if (bt == 0) continue;
             const int g = P.label[t];
@@ -178,8 +183,7 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
 
 hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
-    const int blocks = (B + PB - 1) / PB;
-    hipLaunchKernelGGL(bk_encode_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const unsigned char*>(d_pos), B,
+    hipLaunchKernelGGL(bk_encode_kernel, dim3(B), dim3(128), 0, stream, static_cast<const unsigned char*>(d_pos), B,
                        d_planes);
     return hipGetLastError();
 }

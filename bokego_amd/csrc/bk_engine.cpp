@@ -446,13 +446,15 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     if (B > 0) {
         std::memcpy(s->h_in, src, bytes);
         HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, e->s_in));
+        if (src_kind == kSrcPositions) {
+            // the encoder runs on the copy-in stream: small workgroups (2.8 KB LDS) that fit beside the
+            // 3-board leaf workgroups of the previous request still running on the compute stream
+            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->s_in));
+            e->st.positions_encoded += (uint64_t)B;
+        }
         HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
         *s->h_flag = 0;
         HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
-        if (src_kind == kSrcPositions) {
-            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->stream));
-            e->st.positions_encoded += (uint64_t)B;
-        }
         if (e->precision == BK_PRECISION_F16X2) HIP_TRY(e, hipMemsetAsync(s->d_flag, 0, sizeof(unsigned int), e->stream));
         rc = enqueue(e, s->d_in, dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
                      e->precision, s->d_flag);
