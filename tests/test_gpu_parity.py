@@ -236,3 +236,16 @@ def test_c_abi_from_plain_c(gold):
     v = float(out.stdout.split("value=")[1].split()[0])
     f, n = gold
     assert abs(p - 0.818645) < 1e-5 and abs(v - float(n["values_b1"][0])) < 1e-4
+
+
+def test_hard_positions_worst_of_49k(engine):
+    """The 48 positions, out of 49,152 seeded random playouts, on which the f16x2 and the exact-fp32 kernel
+    differ most (tools/precision_sweep.py), with the reference's own outputs (tools/gen_hard_golden.py);
+    |logit| reaches 65 there.  Both kernels must stay inside the tolerance against the reference, and no
+    further from the float64 ground truth than 2x the reference's own fp32 rounding."""
+    h = np.load(os.path.join(GOLDEN, "hard_positions.npz"))
+    out = engine.eval(h["features"], logits=True, probs=False, value=True)
+    assert np.abs(out["logits"] - h["logits"]).max() < TOL_LOGIT
+    assert np.abs(out["value"] - h["values"]).max() < TOL_VALUE
+    ref_noise = np.abs(h["logits"] - h["logits_f64"]).max()
+    assert np.abs(out["logits"] - h["logits_f64"]).max() < 2 * ref_noise

@@ -68,3 +68,11 @@ def test_playout_positions(nets):
     f = p["features"].astype(np.float32)
     assert np.abs(nets[0](f) - p["logits"]).max() < TOL_LOGIT
     assert np.abs(nets[1](f) - p["values"]).max() < TOL_VALUE
+
+
+def test_hard_positions(nets):
+    """Reference outputs on the 48 hardest of 49,152 random-playout positions (|logit| up to 65)."""
+    h = np.load(os.path.join(GOLDEN, "hard_positions.npz"))
+    f = h["features"].astype(np.float32)
+    assert np.abs(nets[0](f) - h["logits"]).max() < TOL_LOGIT
+    assert np.abs(nets[1](f) - h["values"]).max() < TOL_VALUE
