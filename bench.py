@@ -55,10 +55,28 @@ def measured_traffic(batch):
     return d.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pw, vw, x, target_s=12.0):
     from oracle.oracle import OraclePolicy, OracleValue, set_threads
 
     P, V = OraclePolicy(pw), OracleValue(vw)
+    # single thread first: one position at a time, and a 64-position batch
+    set_threads(1)
+    P(x[:1]); V(x[:1])
+    t0 = time.time()
+    for i in range(8):
+        P(x[i:i + 1]); V(x[i:i + 1])
+    b1_ms = (time.time() - t0) / 8 * 1e3
+    t0 = time.time(); P(x[:64]); V(x[:64]); one_thread = 64 / (time.time() - t0)
     # a 1-GPU box gets a 16-core share of the host (more threads only fight over them)
     cores = set_threads(int(os.environ.get("BK_CPU_THREADS", min(16, len(os.sched_getaffinity(0))))))
     n = 64
@@ -69,7 +87,9 @@ def cpu_baseline(pw, vw, x, target_s=12.0):
         P(x); V(x)
     dt = time.time() - t0
     return {"value": reps * len(x) / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} passes over the same {len(x)}-position batch, oracle/nnet_ref.c (OpenMP, fp32), {dt:.1f}s"}
+            "sample": f"{reps} passes over the same {len(x)}-position batch, oracle/nnet_ref.c (OpenMP, fp32), {dt:.1f}s",
+            "cpu_model": cpu_model(), "host_cpus_visible": len(os.sched_getaffinity(0)),
+            "one_thread_leaf_evals_per_s": one_thread, "one_thread_batch1_ms_per_leaf_eval": b1_ms}
 
 
 def selfplay_cpu_baseline(pw, vw, plies_per_game, moves=3, rollouts=400, cores=16):
