@@ -145,7 +145,7 @@ def main():
 
     g = os.path.join(REPO, "tests", "golden")
     pw, vw = load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw"))
-    eng = LeafEngine(pw, vw, device_id=local_rank, max_batch=args.batch, precision=args.precision)
+    eng = LeafEngine(pw, vw, device_id=local_rank, max_batch=max(args.batch, 8192), precision=args.precision)
     x_host, x_recs = make_workload(args.batch, rank)
     x = torch.from_numpy(x_host).cuda()
 
@@ -227,7 +227,7 @@ def main():
         ev = selfplay.EngineEvaluator(eng)
         barrier()
         threads = max(1, min(16, len(os.sched_getaffinity(0)) // world))  # host cores are shared by the ranks
-        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=args.batch, threads=threads,
+        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
                                           reduce_device=torch.device("cuda", local_rank))
         secs = local["seconds"]
         if dist is not None:
