@@ -11,7 +11,6 @@ with `child_stats()` / `N` of the root's children rather than through dicts keye
 """
 import ctypes
 
-import numpy as np
 
 from . import go, nnet, selfplay
 

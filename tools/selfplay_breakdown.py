@@ -1,7 +1,7 @@
 """Where a self-play generation's wall time goes on the host: blocked on the GPU (wait), tree work (deliver +
 the advance half of collect), feature encoding, submit.  usage (GPU box): python tools/selfplay_breakdown.py [pools] [host|gpu]  (where the planes are encoded)"""
 import os, sys, time
-import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401
 from bokego_amd import selfplay
