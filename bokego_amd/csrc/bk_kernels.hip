@@ -302,7 +302,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NB>
 __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a) {
     using G = Geo<NB>;
-    constexpr int MT = G::MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem;
     const int dummy_addr = G::NPOS * 128 + threadIdx.x;
