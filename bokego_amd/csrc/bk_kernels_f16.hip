@@ -66,23 +66,59 @@ struct Geo {
     static constexpr int LDS_BYTES = NPOS * 512 + DUMMY_BYTES + HS_FLOATS * 4;
 };
 
-// Flat row index r of the workgroup's GEMM -> board point.  NB == 3 uses a y-major order so that
-// tile 0 holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding
-// rows each, tiles 1..6 the 189 points with y in 1..7): a 3x3 tap with dy=-1 reads only zero halo
-// for tile 0 and one with dy=+1 only zero halo for tile 7, so those MFMAs are skipped.
+// LDS swizzle key of an activation record: its 16-B chunks are stored at chunk ^ key.  A reader of tap
+// (dy,dx) addresses the neighbour's record, whose key is the reader's own key + 9dy + dx, so a lane group
+// whose rows have 16 distinct keys reads 16 distinct bank slots at every tap.
 template <int NB>
-__device__ __forceinline__ bool row_decode(int r, int& b, int& y, int& x) {
+__device__ __forceinline__ int act_key(int b, int y, int x) {
+    return NB == 3 ? 6 * b + 9 * (y - 1) + x + 16 : 81 * b + 9 * y + x;  // only the low 4 bits are used
+}
+
+// Rows of the two edge tiles of the NB == 3 order: (board, x) of the y=0 / y=8 point handled by each of
+// the 32 lanes (-1: padding row) and the row's swizzle key.  The 27 points are dealt to the lanes so that
+// each ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} holds 16 distinct keys, padding rows
+// taking the keys left over (tools/lds_layout.py generates and checks these tables).
+__device__ constexpr signed char kEdgeB[2][32] = {
+    {1, 1, 1, 0, 2, 2, 2, 2, 2, 2, 2, 2, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 0, -1, -1, 2, -1, -1, -1},
+    {0, 0, 0, 0, 2, 2, 2, 2, 1, 1, 1, 2, 0, 0, 0, 1, 2, 2, 2, 1, 1, 1, 0, 0, 1, 2, -1, -1, 1, -1, -1, -1}};
+__device__ constexpr signed char kEdgeX[2][32] = {
+    {6, 7, 8, 0, 0, 1, 2, 4, 5, 6, 7, 8, 1, 2, 3, 4, 0, 1, 2, 4, 6, 7, 8, 3, 5, 5, 0, 0, 3, 0, 0, 0},
+    {1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2, 0, 6, 7, 8, 6, 1, 2, 4, 3, 7, 8, 0, 5, 4, 3, 0, 0, 5, 0, 0, 0}};
+__device__ constexpr signed char kEdgeKey[2][32] = {
+    {3, 4, 5, 7, 3, 4, 5, 7, 8, 9, 10, 11, 8, 9, 10, 11, 13, 14, 15, 1, 13, 14, 15, 0, 2, 12, 1, 6, 6, 0, 2, 12},
+    {0, 1, 2, 3, 0, 1, 2, 3, 5, 6, 7, 11, 5, 6, 7, 11, 12, 13, 15, 8, 12, 13, 15, 4, 9, 14, 8, 10, 10, 4, 9, 14}};
+
+// Flat row index r of the workgroup's GEMM -> board point and swizzle key.  NB == 3 uses a y-major order so
+// that tile 0 holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding
+// rows each): a 3x3 tap with dy=-1 reads only zero halo for tile 0 and one with dy=+1 only zero halo for
+// tile 7, so those MFMAs are skipped.  Tiles 1..6 hold the points with y in 1..7, two tiles per board
+// (63 points + 1 padding row), in (y,x) order: consecutive rows have consecutive keys.
+template <int NB>
+__device__ __forceinline__ bool row_decode(int r, int& b, int& y, int& x, int& key) {
     bool valid;
     if (NB == 3) {
-        if (r < 32) { valid = r < 27; b = r / 9; y = 0; x = r - 9 * b; }
-        else if (r < 224) { const int i = r - 32; valid = i < 189; b = i / 63; const int j = i - 63 * b; y = 1 + j / 9; x = j - 9 * (y - 1); }
-        else { const int i = r - 224; valid = i < 27; b = i / 9; y = 8; x = i - 9 * b; }
+        if (r < 32 || r >= 224) {
+            const int e = r >= 224, l = r & 31;
+            b = kEdgeB[e][l];
+            x = kEdgeX[e][l];
+            key = kEdgeKey[e][l];
+            y = e ? 8 : 0;
+            valid = b >= 0;
+        } else {
+            const int i = r - 32, j = i & 63;
+            b = i >> 6;
+            valid = j < 63;
+            y = 1 + j / 9;
+            x = j - 9 * (y - 1);
+            key = act_key<NB>(b, y, x);  // the padding row j = 63 continues the sequence
+        }
     } else {
         valid = r < 81 * NB;
         b = r / 81;
         const int q = r - 81 * b;
         y = q / 9;
         x = q - 9 * y;
+        key = act_key<NB>(b, y, x);
     }
     if (!valid) { b = 0; y = NB == 3 ? 4 : 0; x = 0; }  // padding rows compute from a valid address; never stored
     return valid;
@@ -106,7 +142,9 @@ __device__ __forceinline__ void sched_pattern(std::integer_sequence<int, I...>) 
 // planes are small integers, so in practice always).
 template <int NB, bool FIRST, int NPROD = 3>
 __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* __restrict__ wl,
-                                             f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
+                                             f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn,
+                                             const int (&rpos3)[Geo<NB>::MTW], const int (&rpos5)[Geo<NB>::MTW],
+                                             const int (&rkey)[Geo<NB>::MTW]) {
     constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
     constexpr int KW = FIRST ? 5 : 3;
     constexpr int TAPS = KW * KW;
@@ -114,15 +152,13 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
     constexpr int NSTEPS = FIRST ? BK16_L0_STEPS : TAPS * S;  // layer 0 is zero-padded to a multiple of 4
     constexpr int ROWB = FIRST ? 128 : 512;               // bytes per position
     constexpr int LO = FIRST ? 64 : 256;                  // hi plane -> lo plane
-    const int h = lane >> 5, l32 = lane & 31;
+    const int h = lane >> 5;
 
     int pbase[MTW], rrow[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        int b, y, x;
-        row_decode<NB>((wm * MTW + mt) * 32 + l32, b, y, x);
-        pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
-        rrow[mt] = 81 * b + 9 * y + x;
+        pbase[mt] = FIRST ? rpos5[mt] : rpos3[mt];
+        rrow[mt] = rkey[mt];
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -153,8 +189,8 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
         for (int mt = 0; mt < MTW; ++mt) {
             const int pa = pbase[mt] + off;
             ab[mt] = pa * ROWB;
-            // swizzle key of the position being read = low bits of ITS flat row index r + 9dy + dx
-            // (the writer's key): the 16 lanes of a ds_read_b128 group then hit 16 distinct slots.
+            // swizzle key of the position being read = this row's key + 9dy + dx (= the writer's key,
+            // act_key): the 16 lanes of a ds_read_b128 group then hit 16 distinct slots.
             // Out-of-board neighbours land in all-zero halo rows, where any key reads zeros.
             swb[mt] = (FIRST ? ((pa >> 1) & 3) : ((rrow[mt] + 9 * (ky - 1) + (kx - 1)) & 15)) << 4;
         }
@@ -319,6 +355,18 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     f32x16 acc[MTW][NT];
     const int wm = wave / G::WN, wn = wave - wm * G::WN;
 
+    // this lane's GEMM rows (one per position tile of the wave): decoded once, the edge tiles read tables
+    int rpos3[MTW], rpos5[MTW], rkey[MTW], rstore[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        int b, y, x, k;
+        const bool valid = row_decode<NB>((wm * MTW + mt) * 32 + l32, b, y, x, k);
+        rpos3[mt] = pos3(b, y, x);
+        rpos5[mt] = pos5(b, y, x);
+        rkey[mt] = k & 15;
+        rstore[mt] = valid ? rpos3[mt] * 512 : -1;
+    }
+
     // epilogue: acc register 4q+j of (mt, nt) = cout 32*(wn*NT+nt) + 8q + 4h + j at this lane's position
     float umax = 0.f;  // largest pre-clamp activation seen by this lane (inf if anything overflowed)
     auto store = [&](int L) {
@@ -326,11 +374,8 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
         const float* bias = P.bias16 + L * 128;         // sa_out * folded bias
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            int b, y, x;
-            const bool valid = row_decode<NB>((wm * MTW + mt) * 32 + l32, b, y, x);
-            const int p = pos3(b, y, x);
-            const int rowb = valid ? p * 512 : -1;
-            const int key = ((81 * b + 9 * y + x) & 15) << 4;
+            const int rowb = rstore[mt];
+            const int key = rkey[mt] << 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -358,8 +403,8 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     };
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    if (need_lo) conv_layer16<NB, true, 3>(actb, P.wfrag16, acc, lane, wm, wn);
-    else conv_layer16<NB, true, 2>(actb, P.wfrag16, acc, lane, wm, wn);
+    if (need_lo) conv_layer16<NB, true, 3>(actb, P.wfrag16, acc, lane, wm, wn, rpos3, rpos5, rkey);
+    else conv_layer16<NB, true, 2>(actb, P.wfrag16, acc, lane, wm, wn, rpos3, rpos5, rkey);
     STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -373,7 +418,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        conv_layer16<NB, false>(actb, P.wfrag16 + BK16_L0_HALFS + (size_t)(L - 1) * BK16_L3_HALFS, acc, lane, wm, wn);
+        conv_layer16<NB, false>(actb, P.wfrag16 + BK16_L0_HALFS + (size_t)(L - 1) * BK16_L3_HALFS, acc, lane, wm, wn, rpos3, rpos5, rkey);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
@@ -394,7 +439,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
             const int q = lane + 64 * k;
             float d = 0.f;
             if (q < 81) {
-                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x), key = (81 * wave + q) & 15;
+                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x), key = act_key<NB>(wave, y, x) & 15;
                 const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
 #pragma unroll 4
                 for (int g = 0; g < 16; ++g) {
