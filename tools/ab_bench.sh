@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B on the same box: alternate old/new library, 3 rounds
+# A/B on one GPU box: alternates bokego_amd/libbokego_amd_old.so (tools/build_ref_lib.sh <ref>) and the current build, 3 rounds
 for i in 1 2 3; do
   for v in old new; do
     L=$PWD/bokego_amd/libbokego_amd.so; [ $v = old ] && L=$PWD/bokego_amd/libbokego_amd_old.so
