@@ -49,6 +49,18 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+// v - (float)h[0] / v - (float)h[1] as one mixed-precision FMA (fp16 source operand, fp32 result)
+__device__ __forceinline__ float sub_f16_lo(float v, f16x2 h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float v, f16x2 h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ int pos3(int b, int y, int x) { return (10 * b + 1 + y) * 10 + x + 1; }
 __device__ __forceinline__ int pos5(int b, int y, int x) { return (11 * b + 2 + y) * 11 + x + 2; }
 
@@ -391,10 +403,14 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
                     }
                     f16x4 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hi[j] = (_Float16)v[j];
-                        lo[j] = (_Float16)(v[j] - (float)hi[j]);
-                    }
+                    for (int j = 0; j < 4; ++j) hi[j] = (_Float16)v[j];
+                    // lo = fp16(v - hi): v - hi is exact in fp32; v_fma_mix_f32 reads hi straight from its packed
+                    // fp16 register (one VALU op instead of convert + subtract)
+                    const f16x2 h01 = {hi[0], hi[1]}, h23 = {hi[2], hi[3]};
+                    lo[0] = (_Float16)sub_f16_lo(v[0], h01);
+                    lo[1] = (_Float16)sub_f16_hi(v[1], h01);
+                    lo[2] = (_Float16)sub_f16_lo(v[2], h23);
+                    lo[3] = (_Float16)sub_f16_hi(v[3], h23);
                     const int addr = rowb >= 0 ? rowb + ((((c0 >> 3) << 4) ^ key) | (8 * h)) : dummy_addr;
                     *reinterpret_cast<f16x4*>(actb + addr) = hi;
                     *reinterpret_cast<f16x4*>(actb + addr + 256) = lo;

@@ -11,7 +11,7 @@ import bench
 
 G = os.path.join(REPO, "tests", "golden")
 e = LeafEngine(load_bkw(f"{G}/policy_19.bkw"), load_bkw(f"{G}/value_synth.bkw"), max_batch=4096)
-x = bench.make_workload(4096, 1)
+x = bench.make_workload(4096, 1)[0]
 for _ in range(3):
     e.eval(x, logits=False, probs=True, value=True)
 nblk = 2 * ((4096 + 2) // 3)
