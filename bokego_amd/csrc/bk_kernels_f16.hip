@@ -381,9 +381,20 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
 
     // epilogue: acc register 4q+j of (mt, nt) = cout 32*(wn*NT+nt) + 8q + 4h + j at this lane's position
     float umax = 0.f;  // largest pre-clamp activation seen by this lane (inf if anything overflowed)
-    auto store = [&](int L) {
-        const float cs = P.cscale16[L];                 // sa_out / (sa_in * sw_L): a power of two
-        const float* bias = P.bias16 + L * 128;         // sa_out * folded bias
+    // the layer's folded biases for this lane's couts (sa_out * bias) and its output scale: fetched before the
+    // barrier that precedes the epilogue, so the loads fly while the wave waits for the others
+    f32x4 bvec[NT * 4];
+    float cs = 0.f;
+    auto load_bias = [&](int L) {
+        cs = P.cscale16[L];                             // sa_out / (sa_in * sw_L): a power of two
+        const float* bias = P.bias16 + L * 128;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bvec[nt * 4 + q] = *reinterpret_cast<const f32x4*>(bias + 32 * (wn * NT + nt) + 8 * q + 4 * h);
+    };
+    auto store = [&]() {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
             const int rowb = rstore[mt];
@@ -393,7 +404,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c0 = 32 * (wn * NT + nt) + 8 * q + 4 * h;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0);
+                    const f32x4 bv = bvec[nt * 4 + q];
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -422,11 +433,12 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     if (need_lo) conv_layer16<NB, true, 3>(actb, P.wfrag16, acc, lane, wm, wn, rpos3, rpos5, rkey);
     else conv_layer16<NB, true, 2>(actb, P.wfrag16, acc, lane, wm, wn, rpos3, rpos5, rkey);
     STAMP(2);
+    load_bias(0);
     __syncthreads();
     for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     STAMP(3);
-    store(0);
+    store();
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -436,9 +448,10 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     for (int L = 1; L < 7; ++L) {
         conv_layer16<NB, false>(actb, P.wfrag16 + BK16_L0_HALFS + (size_t)(L - 1) * BK16_L3_HALFS, acc, lane, wm, wn, rpos3, rpos5, rkey);
         STAMP(2 + 4 * L);
+        load_bias(L);
         __syncthreads();
         STAMP(3 + 4 * L);
-        store(L);
+        store();
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
