@@ -460,35 +460,35 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     // an activation beyond the fp16 range was clamped: tell the host, which re-runs the batch in fp32
     if (__any(!(umax < 65504.f)) && lane == 0 && a.overflow) atomicOr(a.overflow, 1u);
 
-    // ---- heads: wave w handles board w (activations = (hi + lo) * inv_sa) ----
+    // ---- heads.  1x1 conv (untied bias): one thread per board point over all 4 waves, results to LDS;
+    //      then wave w finishes board w (activations = (hi + lo) * inv_sa) ----
+    if (tid < 81 * nb) {
+        const int bb = tid / 81, q = tid - 81 * bb;
+        const int y = q / 9, x = q - 9 * y, p = pos3(bb, y, x), key = act_key<NB>(bb, y, x) & 15;
+        const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
+        float d = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const char* src = actb + p * 512 + ((g ^ key) << 4);
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(src);
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(src + 256);
+            const f32x4 w0 = hw[2 * g], w1 = hw[2 * g + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d += ((float)vh[j] + (float)vl[j]) * w0[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[j];
+            }
+        }
+        hs[bb * 96 + q] = d * P.inv_sa16 + P.head_b[q];
+    }
+    __syncthreads();
     if (wave < nb) {
         float s[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = lane + 64 * k;
-            float d = 0.f;
-            if (q < 81) {
-                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x), key = act_key<NB>(wave, y, x) & 15;
-                const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
-#pragma unroll 4
-                for (int g = 0; g < 16; ++g) {
-                    const char* src = actb + p * 512 + ((g ^ key) << 4);
-                    const f16x8 vh = *reinterpret_cast<const f16x8*>(src);
-                    const f16x8 vl = *reinterpret_cast<const f16x8*>(src + 256);
-                    const f32x4 w0 = hw[2 * g], w1 = hw[2 * g + 1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        d += ((float)vh[j] + (float)vl[j]) * w0[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        d += ((float)vh[4 + j] + (float)vl[4 + j]) * w1[j];
-                    }
-                }
-                d = d * P.inv_sa16 + P.head_b[q];
-            }
-            s[k] = d;
-        }
+        s[0] = hs[wave * 96 + lane];
+        s[1] = lane + 64 < 81 ? hs[wave * 96 + lane + 64] : 0.f;
         const int bg = b0 + wave;
         if (net == 0) {
             float m = fmaxf(s[0], (lane + 64 < 81) ? s[1] : -INFINITY);
