@@ -222,15 +222,15 @@ __device__ __forceinline__ void conv_layer16(const char* actb, const _Float16* _
 
     // MLO..MHI: the position tiles of this wave that take part (tap skipping, see row_decode)
     auto mma = [&](auto MLO, auto MHI, const f16x8 (&X)[MTW][2], const f16x8 (&W)[NT][2]) {
+        // product-major order: consecutive MFMAs write different accumulator tiles (no back-to-back dependence)
 #pragma unroll
-        for (int mt = decltype(MLO)::value; mt < decltype(MHI)::value; ++mt)
+        for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][0], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], X[mt][0], acc[mt][nt], 0, 0, 0);
-                if (NPROD == 3)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], X[mt][1], acc[mt][nt], 0, 0, 0);
-            }
+            for (int mt = decltype(MLO)::value; mt < decltype(MHI)::value; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][pr == 1 ? 1 : 0], X[mt][pr == 2 ? 1 : 0],
+                                                                         acc[mt][nt], 0, 0, 0);
     };
 
     // step ks: X(ks+1) is read from LDS and W(ks+3) fetched from L2 while step ks's MFMAs run
