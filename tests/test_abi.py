@@ -111,3 +111,26 @@ def test_host_library_exports_go_and_tree_headers():
             assert hasattr(lib, f)
     assert lib.bk_go_abi_version() == 1
     assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 48 and C.sizeof(selfplay.GameInfo) == 56
+
+
+def test_lds_edge_tables_match_generator():
+    """The edge-tile row tables compiled into bk_kernels_f16.hip are the ones tools/lds_layout.py generates, and the
+    generator's bank model says every ds_read_b128 lane group is conflict-free with them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_layout", os.path.join(REPO, "tools", "lds_layout.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = open(os.path.join(REPO, "bokego_amd", "csrc", "bk_kernels_f16.hip")).read()
+
+    def table(name):
+        body = re.search(name + r"\[2\]\[32\] = \{(.*?)\};", src, flags=re.S).group(1)
+        rows = re.findall(r"\{([^{}]*)\}", body)
+        return [[int(v) for v in r.split(",")] for r in rows]
+
+    B, X, K = table("kEdgeB"), table("kEdgeX"), table("kEdgeKey")
+    for e, y in enumerate((0, 8)):
+        lanes, keys = m.edge_tile(y)
+        assert B[e] == [it[0] if it else -1 for it in lanes]
+        assert X[e] == [it[1] if it else 0 for it in lanes]
+        assert K[e] == keys
+    assert m.cycles(m.new_rows()) == 1.0 and m.cycles(m.old_rows()) > 1.3
