@@ -249,3 +249,54 @@ def test_hard_positions_worst_of_49k(engine):
     assert np.abs(out["value"] - h["values"]).max() < TOL_VALUE
     ref_noise = np.abs(h["logits"] - h["logits_f64"]).max()
     assert np.abs(out["logits"] - h["logits_f64"]).max() < 2 * ref_noise
+
+
+def _random_nets(seed, gain):
+    """Seeded random PolicyNet / ValueNet tensors with the reference's names and shapes (nnet.py:31-57,73-101):
+    conv weights ~ N(0, gain^2 / fan_in), non-trivial BatchNorm statistics everywhere."""
+    rng = np.random.default_rng(seed)
+
+    def trunk():
+        t = {}
+        for l, (c, b) in enumerate(zip((0, 3, 6, 9, 12, 15, 18), (1, 4, 7, 10, 13, 16, 19))):
+            cin, k = (27, 5) if l == 0 else (128, 3)
+            t[f"conv.{c}.weight"] = (rng.standard_normal((128, cin, k, k)) * gain / np.sqrt(cin * k * k)).astype(np.float32)
+            t[f"conv.{c}.bias"] = (rng.standard_normal(128) * 0.1).astype(np.float32)
+            t[f"conv.{b}.weight"] = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+            t[f"conv.{b}.bias"] = (rng.standard_normal(128) * 0.2).astype(np.float32)
+            t[f"conv.{b}.running_mean"] = (rng.standard_normal(128) * 0.2).astype(np.float32)
+            t[f"conv.{b}.running_var"] = rng.uniform(0.5, 2.0, 128).astype(np.float32)
+        t["conv.21.weight"] = (rng.standard_normal((1, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
+        t["conv.21.bias"] = (rng.standard_normal((1, 9, 9)) * 0.1).astype(np.float32)
+        return t
+
+    p, v = trunk(), trunk()
+    v.update({"bn.weight": np.float32([1.3]), "bn.bias": np.float32([0.2]), "bn.running_mean": np.float32([-0.1]),
+              "bn.running_var": np.float32([0.7]),
+              "lin1.weight": (rng.standard_normal((64, 81)) / 9).astype(np.float32), "lin1.bias": (rng.standard_normal(64) * 0.1).astype(np.float32),
+              "lin_bn.weight": rng.uniform(0.5, 1.5, 64).astype(np.float32), "lin_bn.bias": (rng.standard_normal(64) * 0.1).astype(np.float32),
+              "lin_bn.running_mean": (rng.standard_normal(64) * 0.2).astype(np.float32), "lin_bn.running_var": rng.uniform(0.5, 2.0, 64).astype(np.float32),
+              "lin2.weight": (rng.standard_normal((1, 64)) / 8).astype(np.float32), "lin2.bias": np.float32([0.05])})
+    return p, v
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("seed,gain", [(1, 1.0), (2, 1.6), (3, 0.5)])
+def test_random_weights_vs_oracle(gold, precision, seed, gain):
+    """Nets the kernels were never tuned on (other weight scales -> other per-layer fp16 scale exponents, other
+    BatchNorm folds): outputs still agree with the CPU oracle at fp32 level, relative to the logit magnitude."""
+    from bokego_amd.engine import LeafEngine
+    from oracle.oracle import OraclePolicy, OracleValue
+    pw, vw = _random_nets(seed, gain)
+    x = gold[0][::7].astype(np.float32)
+    eng = LeafEngine(pw, vw, max_batch=128, precision=precision)
+    out = eng.eval(x, logits=True, probs=True, value=True)
+    st = eng.stats()
+    eng.close()
+    lg, pr = OraclePolicy(pw)(x, want_probs=True)
+    va = OracleValue(vw)(x)
+    scale = max(1.0, float(np.abs(lg).max()) / 15.0)      # the goldens' logits reach ~15 at TOL_LOGIT
+    assert np.abs(out["logits"] - lg).max() < TOL_LOGIT * scale
+    assert np.abs(out["probs"] - pr).max() < TOL_PROB * 2
+    assert np.abs(out["value"] - va).max() < TOL_VALUE
+    assert np.isfinite(out["logits"]).all() and st["f16_overflow_fallbacks"] in (0, 1)
