@@ -1,0 +1,100 @@
+"""Native RCCL all-reduce of the self-play statistics (libbkcomm.so, include/bokego_comm.h).
+
+The Python drivers normally use torch.distributed (backend "nccl" is RCCL on ROCm) for the one collective
+of the path; this module is the same step through the C ABI, as a host without torch would do it:
+
+    comm = NativeComm.create(rank, world, device_id, "/tmp/bk_comm_id")   # rank 0 writes the id file
+    totals = comm.allreduce_sum(local_stats)                              # np.float64 vector, <= 4096
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+COMM_LIB_PATH = os.environ.get("BK_COMM_LIB_PATH") or os.path.join(_HERE, "libbkcomm.so")
+ID_BYTES = 128
+_VP = ctypes.c_void_p
+
+# every symbol include/bokego_comm.h declares
+COMM_SYMBOLS = {
+    "bk_comm_abi_version": (ctypes.c_int, []),
+    "bk_comm_unique_id": (ctypes.c_int, [_VP]),
+    "bk_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, ctypes.POINTER(_VP)]),
+    "bk_comm_allreduce_sum_f64": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
+    "bk_comm_rank": (ctypes.c_int, [_VP]),
+    "bk_comm_world": (ctypes.c_int, [_VP]),
+    "bk_comm_destroy": (ctypes.c_int, [_VP]),
+    "bk_comm_last_error": (ctypes.c_char_p, []),
+}
+_lib = None
+
+
+def commlib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(COMM_LIB_PATH):
+            raise RuntimeError(f"{COMM_LIB_PATH} not found: build it with `make -C bokego_amd/csrc`")
+        try:
+            import torch  # noqa: F401  (same reason as in _lib.py: one HIP/RCCL runtime per process)
+        except ImportError:
+            pass
+        lib = ctypes.CDLL(COMM_LIB_PATH)
+        for name, (res, args) in COMM_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class NativeComm:
+    def __init__(self, rank, world, device_id, unique_id):
+        self._lib = commlib()
+        if len(unique_id) != ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        self._h = _VP()
+        buf = (ctypes.c_uint8 * ID_BYTES).from_buffer_copy(bytes(unique_id))
+        if self._lib.bk_comm_init(int(rank), int(world), buf, int(device_id), ctypes.byref(self._h)):
+            raise RuntimeError("bk_comm_init: " + self._lib.bk_comm_last_error().decode())
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * ID_BYTES)()
+        lib = commlib()
+        if lib.bk_comm_unique_id(buf):
+            raise RuntimeError("bk_comm_unique_id: " + lib.bk_comm_last_error().decode())
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, rank, world, device_id, id_path, timeout=120.0):
+        """Rendezvous through a file every rank can see: rank 0 writes the id, the others wait for it."""
+        if rank == 0:
+            uid = cls.unique_id()
+            tmp = f"{id_path}.{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, id_path)
+        else:
+            t0 = time.time()
+            while not (os.path.exists(id_path) and os.path.getsize(id_path) == ID_BYTES):
+                if time.time() - t0 > timeout:
+                    raise RuntimeError(f"no communicator id at {id_path} after {timeout}s")
+                time.sleep(0.01)
+            uid = open(id_path, "rb").read()
+        return cls(rank, world, device_id, uid)
+
+    def allreduce_sum(self, vec):
+        a = np.ascontiguousarray(vec, np.float64).copy()
+        if self._lib.bk_comm_allreduce_sum_f64(self._h, a.ctypes.data, a.size):
+            raise RuntimeError("bk_comm_allreduce_sum_f64: " + self._lib.bk_comm_last_error().decode())
+        return a
+
+    def close(self):
+        if self._h:
+            self._lib.bk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -264,8 +264,13 @@ def pool_stats(pools):
     return s
 
 
-def all_reduce_stats(stats, device=None):
-    """The generation's single collective: sum the statistics vector over ranks (no process group: no-op)."""
+def all_reduce_stats(stats, device=None, native_comm=None):
+    """The generation's single collective: sum the statistics vector over ranks (no process group: no-op).
+    native_comm: a bokego_amd.comm.NativeComm -- the same all-reduce through libbkcomm.so instead of torch."""
+    if native_comm is not None:
+        t0 = time.perf_counter()
+        out = native_comm.allreduce_sum(stats)
+        return out, time.perf_counter() - t0
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -286,7 +291,7 @@ def shard_game_ids(n_games, rank, world):
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
-              reduce_device=None, progress=None, prune=1, record_visits=0):
+              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict)."""
     gids = shard_game_ids(n_games, rank, world)
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
@@ -306,7 +311,7 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
             if record_visits:
                 visits[g] = [pool.visits(i, ply) for ply in range(len(games[g]["moves"]))]
     local = pool_stats(pools) if pools else np.zeros(STATS_LEN)
-    total, t_reduce = all_reduce_stats(local, reduce_device)
+    total, t_reduce = all_reduce_stats(local, reduce_device, native_comm)
     for p in pools:
         p.close()
     named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}

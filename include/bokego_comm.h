@@ -1,0 +1,45 @@
+/*
+ * bokego_comm.h -- C ABI of the one collective on the path: the end-of-generation reduction of self-play
+ * statistics over the GPUs of a node (libbkcomm.so = RCCL over xGMI behind plain pointers).
+ *
+ * The reference has no collective: its workers append to a multiprocessing Manager().list()
+ * (bin/selfplay.py:179-180,201-204) and the parent sums.  Here every rank (one process per GPU) plays its
+ * shard of the games (game id % world) with no communication, then ONE all-reduce(sum) of a short fp64
+ * vector [games, black wins, white wins, plies, sum of scores, value evals, policy evals, requests,
+ * first-move histogram[81]] gives every rank the generation's totals.  The Python host uses
+ * torch.distributed (backend "nccl" = the same RCCL) for this; libbkcomm.so is the same step for hosts
+ * without Python/torch.
+ *
+ * Bootstrap: rank 0 calls bk_comm_unique_id and hands the 128 bytes to the other ranks by whatever the
+ * launcher offers (file, socket, environment); then every rank calls bk_comm_init.
+ */
+#ifndef BOKEGO_COMM_H
+#define BOKEGO_COMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_COMM_ID_BYTES 128
+
+typedef struct bk_comm bk_comm;
+
+int bk_comm_abi_version(void);
+/* rank 0: create the rendezvous id (ncclGetUniqueId) */
+int bk_comm_unique_id(uint8_t id[BK_COMM_ID_BYTES]);
+/* every rank: join; device_id = the GPU this process drives (normally the local rank) */
+int bk_comm_init(int rank, int world, const uint8_t id[BK_COMM_ID_BYTES], int device_id, bk_comm **out);
+/* in-place sum over all ranks of a host fp64 vector (n <= 4096): one ncclAllReduce on the comm's stream */
+int bk_comm_allreduce_sum_f64(bk_comm *c, double *buf, int n);
+int bk_comm_rank(const bk_comm *c);
+int bk_comm_world(const bk_comm *c);
+int bk_comm_destroy(bk_comm *c);
+/* message of the last failure on this thread; 0 = ok, negative = failure as in bokego_amd.h */
+const char *bk_comm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -134,3 +134,23 @@ def test_lds_edge_tables_match_generator():
         assert X[e] == [it[1] if it else 0 for it in lanes]
         assert K[e] == keys
     assert m.cycles(m.new_rows()) == 1.0 and m.cycles(m.old_rows()) > 1.3
+
+
+def test_comm_library_symbols_and_cpu_errors():
+    """libbkcomm.so (RCCL all-reduce of the self-play statistics) exports what include/bokego_comm.h declares and
+    refuses to create a communicator without a GPU."""
+    from bokego_amd import comm
+    lib = comm.commlib()
+    fns = _header_functions("bokego_comm.h")
+    assert set(fns) == set(comm.COMM_SYMBOLS)
+    for f in fns:
+        assert hasattr(lib, f)
+    assert lib.bk_comm_abi_version() == 1
+    import torch
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        ident = (ctypes.c_uint8 * 128)()
+        assert lib.bk_comm_init(0, 1, ident, 0, ctypes.byref(h)) != 0
+        assert b"device_id" in lib.bk_comm_last_error()
+        assert lib.bk_comm_init(2, 1, ident, 0, ctypes.byref(h)) != 0       # rank >= world
+        assert lib.bk_comm_allreduce_sum_f64(None, None, 3) != 0

@@ -1,0 +1,36 @@
+"""-m gpu: the native RCCL all-reduce (libbkcomm.so) -- one-rank communicator on the box's GPU, and the value it
+returns inside self_play's statistics path."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+from bokego_amd import comm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_allreduce_world1(tmp_path):
+    c = comm.NativeComm.create(0, 1, 0, str(tmp_path / "id"))
+    v = np.arange(89, dtype=np.float64) * 1.5 - 7
+    out = c.allreduce_sum(v)
+    assert np.array_equal(out, v) and out is not v
+    assert np.array_equal(c.allreduce_sum(np.zeros(0)), np.zeros(0))
+    with pytest.raises(RuntimeError):
+        c.allreduce_sum(np.zeros(5000))
+    c.close()
+
+
+def test_self_play_statistics_through_native_comm(tmp_path):
+    import os
+    from bokego_amd import selfplay
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    from conftest import GOLDEN
+    eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=2048)
+    ev = selfplay.EngineEvaluator(eng)
+    c = comm.NativeComm.create(0, 1, 0, str(tmp_path / "id"))
+    kw = dict(n_games=6, rollouts=40, expand_thresh=10, max_turns=20, cap=2048)
+    local, total = selfplay.self_play(ev, native_comm=c, **kw)
+    _, plain = selfplay.self_play(ev, **kw)
+    assert total == plain and total["games"] == 6 and local["allreduce_s"] > 0
+    c.close()
