@@ -1,0 +1,159 @@
+/*
+ * bk_selfplay.c -- BASELINE config 4 without Python: a generation of self-play games driven from C through the
+ * four C ABIs (include/bokego_amd.h engine, bokego_go.h records, bokego_tree.h game pools, bokego_comm.h
+ * all-reduce).  The same loop as bokego_amd/selfplay.py:run_pools -- three lock-step pools rotate through one
+ * engine, so the host advances one pool's trees while the GPU evaluates the others' leaves.
+ *
+ *   make -C bokego_amd/csrc examples
+ *   ./examples/bk_selfplay tests/golden/policy_19.bkw tests/golden/value_synth.bkw [games=512] [rollouts=400]
+ *   multi-GPU (one process per GPU): BK_RANK=r BK_WORLD=n BK_COMM_ID_FILE=/shared/path ./examples/bk_selfplay ...
+ *
+ * Games are assigned gid % world and seeded by 20260 + gid, as in the Python driver.  (The priors are
+ * normalised here with a plain left-to-right fp32 sum, torch's Categorical uses a vectorised one, so games can
+ * differ from the Python driver's in the last bit of a prior; each driver is deterministic.)
+ */
+#include <time.h>
+#include <unistd.h>
+
+#include "bkw_load.h"
+#include "bokego_comm.h"
+#include "bokego_go.h"
+#include "bokego_tree.h"
+
+#define CAP 8192
+#define NPOOLS 3
+
+typedef struct {
+    bk_pool *pool;
+    bk_pos *recs;
+    float *probs, *values;
+    int64_t ticket;
+    int n, npol, live, n_games;
+} slot_t;
+
+static double now(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s policy.bkw value.bkw [games] [rollouts]\n", argv[0]); return 2; }
+    const int n_games = argc > 3 ? atoi(argv[3]) : 512, rollouts = argc > 4 ? atoi(argv[4]) : 400;
+    const int rank = getenv("BK_RANK") ? atoi(getenv("BK_RANK")) : 0, world = getenv("BK_WORLD") ? atoi(getenv("BK_WORLD")) : 1;
+    const unsigned char *pf = slurp(argv[1]), *vf = slurp(argv[2]);
+    bk_policy_weights pw;
+    bk_value_weights vw;
+    fill_trunk(&pw.trunk, pf);
+    fill_trunk(&vw.trunk, vf);
+    fill_value_head(&vw.head, vf);
+    const int device = rank % (bk_device_count() > 0 ? bk_device_count() : 1);
+    bk_engine *e = NULL;
+    if (bk_engine_create(&pw, &vw, device, CAP, &e)) { fprintf(stderr, "bk_engine_create: %s\n", bk_last_error(NULL)); return 1; }
+
+    bk_search_params prm;
+    bk_search_params_default(&prm);
+    prm.rollouts = rollouts;
+    prm.noise_weight = 0.25f;
+    prm.sample_plies = 8;
+    prm.prune = 1;
+
+    /* this rank's games, dealt to the pools round-robin */
+    slot_t s[NPOOLS];
+    uint64_t *seeds = malloc(sizeof(uint64_t) * (n_games + 1));
+    int mine = 0;
+    for (int g = rank; g < n_games; g += world) seeds[mine++] = 20260 + (uint64_t)g;
+    const int npools = mine >= 192 ? 3 : (mine >= 2 ? 2 : 1);
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    for (int i = 0; i < npools; ++i) {
+        uint64_t *ps = malloc(sizeof(uint64_t) * (mine / npools + 1));
+        int k = 0;
+        for (int j = i; j < mine; j += npools) ps[k++] = seeds[j];
+        s[i].pool = bk_pool_create(k, &prm, ps, ncpu < 16 ? (int)ncpu : 16);
+        s[i].n_games = k;
+        s[i].recs = malloc(sizeof(bk_pos) * CAP);
+        s[i].probs = malloc(sizeof(float) * 81 * CAP);
+        s[i].values = malloc(sizeof(float) * CAP);
+        s[i].ticket = 0;
+        s[i].live = 1;
+        free(ps);
+    }
+
+    const double t0 = now();
+    long steps = 0, positions = 0;
+    for (int busy = 1; busy;) {
+        busy = 0;
+        for (int i = 0; i < npools; ++i) {
+            slot_t *p = &s[i];
+            if (p->ticket) {
+                if (bk_wait(e, p->ticket)) { fprintf(stderr, "bk_wait: %s\n", bk_last_error(e)); return 1; }
+                for (int r = 0; r < p->npol; ++r) {          /* Categorical(probs) re-normalises (nnet.py:274) */
+                    float sum = 0.f, *row = p->probs + 81 * r;
+                    for (int k = 0; k < 81; ++k) sum += row[k];
+                    for (int k = 0; k < 81; ++k) row[k] /= sum;
+                }
+                bk_pool_deliver(p->pool, p->probs, p->values);
+                p->ticket = 0;
+            }
+            if (p->live) {
+                p->n = bk_pool_collect_pos(p->pool, p->recs, CAP, &p->npol);
+                if (p->n == 0) { p->live = 0; continue; }
+                p->ticket = bk_submit_positions(e, p->recs, p->n, p->npol, (p->npol ? BK_WANT_PROBS : 0) | BK_WANT_VALUE, NULL,
+                                                p->probs, p->values);
+                if (p->ticket < 0) { fprintf(stderr, "bk_submit_positions: %s\n", bk_last_error(e)); return 1; }
+                ++steps;
+                positions += p->n;
+                busy = 1;
+            }
+            busy |= p->ticket != 0;
+        }
+    }
+    const double secs = now() - t0;
+
+    /* statistics vector, as bokego_amd/selfplay.py:pool_stats: 8 scalars + first-move histogram */
+    double st[8 + 81];
+    memset(st, 0, sizeof st);
+    unsigned long long check = 1469598103934665603ull;    /* FNV-1a over every move of every game (determinism check) */
+    for (int i = 0; i < npools; ++i)
+        for (int g = 0; g < s[i].n_games; ++g) {
+            bk_game_info gi;
+            int16_t mv[128];
+            bk_pool_game_info(s[i].pool, g, &gi);
+            const int nm = bk_pool_game_moves(s[i].pool, g, mv, 128);
+            st[0] += 1; st[1] += gi.score > 0; st[2] += gi.score <= 0; st[3] += gi.n_moves; st[4] += gi.score;
+            st[5] += (double)gi.n_value_evals; st[6] += (double)gi.n_policy_evals; st[7] += (double)gi.n_requests;
+            if (nm > 0 && mv[0] >= 0) st[8 + mv[0]] += 1;
+            for (int k = 0; k < nm; ++k) check = (check ^ (unsigned short)mv[k]) * 1099511628211ull;
+        }
+    double reduce_ms = 0;
+    if (world > 1) {
+        const char *idf = getenv("BK_COMM_ID_FILE");
+        uint8_t id[BK_COMM_ID_BYTES];
+        if (!idf) { fprintf(stderr, "BK_WORLD > 1 needs BK_COMM_ID_FILE\n"); return 1; }
+        if (rank == 0) {
+            if (bk_comm_unique_id(id)) { fprintf(stderr, "%s\n", bk_comm_last_error()); return 1; }
+            char tmp[4096];
+            snprintf(tmp, sizeof tmp, "%s.tmp", idf);
+            FILE *f = fopen(tmp, "wb"); fwrite(id, 1, sizeof id, f); fclose(f); rename(tmp, idf);
+        } else {
+            FILE *f;
+            while (!(f = fopen(idf, "rb"))) usleep(10000);
+            if (fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "short id file\n"); return 1; }
+            fclose(f);
+        }
+        bk_comm *c = NULL;
+        if (bk_comm_init(rank, world, id, device, &c)) { fprintf(stderr, "bk_comm_init: %s\n", bk_comm_last_error()); return 1; }
+        const double t1 = now();
+        if (bk_comm_allreduce_sum_f64(c, st, 8 + 81)) { fprintf(stderr, "allreduce: %s\n", bk_comm_last_error()); return 1; }
+        reduce_ms = (now() - t1) * 1e3;
+        bk_comm_destroy(c);
+    }
+    if (rank == 0)
+        printf("{\"games\": %.0f, \"local_games\": %d, \"seconds\": %.4f, \"local_games_per_min\": %.0f, \"steps\": %ld, \"mean_batch\": %.0f, "
+               "\"plies\": %.0f, \"black_wins\": %.0f, \"value_evals\": %.0f, \"policy_evals\": %.0f, \"allreduce_ms\": %.3f, "
+               "\"moves_checksum\": \"%016llx\"}\n",
+               st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms, check);
+    for (int i = 0; i < npools; ++i) bk_pool_destroy(s[i].pool);
+    bk_engine_destroy(e);
+    return 0;
+}

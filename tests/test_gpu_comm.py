@@ -34,3 +34,26 @@ def test_self_play_statistics_through_native_comm(tmp_path):
     _, plain = selfplay.self_play(ev, **kw)
     assert total == plain and total["games"] == 6 and local["allreduce_s"] > 0
     c.close()
+
+
+def test_native_c_self_play_driver():
+    """examples/bk_selfplay.c: config 4's loop from plain C over the four C ABIs (no Python in the loop);
+    deterministic, and the same generation as the Python driver up to last-bit prior normalisation."""
+    import json
+    import os
+    import subprocess
+    from bokego_amd import selfplay
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    from conftest import GOLDEN, REPO
+    exe = os.path.join(REPO, "examples", "bk_selfplay")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "bokego_amd", "csrc"), "examples"])
+    cmd = [exe, os.path.join(GOLDEN, "policy_19.bkw"), os.path.join(GOLDEN, "value_synth.bkw"), "24", "100"]
+    runs = [json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout) for _ in range(2)]
+    assert runs[0]["moves_checksum"] == runs[1]["moves_checksum"]
+    assert runs[0]["games"] == 24 and runs[0]["plies"] == 24 * 81
+    eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=8192)
+    _, total = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=24, rollouts=100, cap=8192)
+    assert total["plies"] == runs[0]["plies"]
+    assert abs(total["value_evals"] - runs[0]["value_evals"]) <= 0.01 * total["value_evals"]
