@@ -52,7 +52,7 @@ def test_native_c_self_play_driver():
     cmd = [exe, os.path.join(GOLDEN, "policy_19.bkw"), os.path.join(GOLDEN, "value_synth.bkw"), "24", "100"]
     runs = [json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout) for _ in range(2)]
     assert runs[0]["moves_checksum"] == runs[1]["moves_checksum"]
-    assert runs[0]["games"] == 24 and runs[0]["plies"] == 24 * 81
+    assert runs[0]["games"] == 24 and 24 * 60 < runs[0]["plies"] <= 24 * 81
     eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=8192)
     _, total = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=24, rollouts=100, cap=8192)
     assert total["plies"] == runs[0]["plies"]
