@@ -30,12 +30,14 @@ struct Slot {  // one in-flight host-buffer request
     int B = 0, n_policy = 0, want = 0;
     float *logits = nullptr, *probs = nullptr, *values = nullptr;  // caller's host buffers
     void* h_in = nullptr;                                          // pinned staging
-    float *h_logits = nullptr, *h_probs = nullptr, *h_values = nullptr;
+    // outputs of a request live in ONE device block and ONE pinned block, laid out per request as
+    // [flag (64 B) | values B | probs n_policy*81 | logits n_policy*81], so a single D2H brings everything back
+    char* h_out = nullptr;
+    char* d_out = nullptr;
+    size_t off_values = 0, off_probs = 0, off_logits = 0, out_bytes = 0;
+    bool flag_dirty = false;  // the device flag was raised: reset it before the slot's next f16x2 launch
     void* d_in = nullptr;
     void* d_pos = nullptr;  // position records (bk_submit_positions): encoded into d_in on the GPU
-    float *d_logits = nullptr, *d_probs = nullptr, *d_values = nullptr;
-    unsigned int* d_flag = nullptr;  // f16x2 overflow flag of this request
-    unsigned int* h_flag = nullptr;
     int dtype = 0;
     hipEvent_t in_ready = nullptr;   // H2D of this request finished (copy-in stream)
     hipEvent_t computed = nullptr;   // kernel of this request finished (compute stream)
@@ -196,18 +198,11 @@ int alloc_slot(bk_engine* e, Slot& s) {
     HIP_TRY(e, hipHostMalloc(&s.h_in, B * 2187 * sizeof(float), hipHostMallocDefault));
     HIP_TRY(e, hipMalloc(&s.d_in, B * 2187 * sizeof(float)));
     HIP_TRY(e, hipMalloc(&s.d_pos, B * BK_POS_BYTES));
-    if (e->has_policy) {
-        HIP_TRY(e, hipHostMalloc((void**)&s.h_logits, B * 81 * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(e, hipHostMalloc((void**)&s.h_probs, B * 81 * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(e, hipMalloc((void**)&s.d_logits, B * 81 * sizeof(float)));
-        HIP_TRY(e, hipMalloc((void**)&s.d_probs, B * 81 * sizeof(float)));
-    }
-    if (e->has_value) {
-        HIP_TRY(e, hipHostMalloc((void**)&s.h_values, B * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(e, hipMalloc((void**)&s.d_values, B * sizeof(float)));
-    }
-    HIP_TRY(e, hipMalloc((void**)&s.d_flag, sizeof(unsigned int)));
-    HIP_TRY(e, hipHostMalloc((void**)&s.h_flag, sizeof(unsigned int), hipHostMallocDefault));
+    const size_t out_max = 64 + B * sizeof(float) + 2 * B * 81 * sizeof(float) + 3 * 64;  // + section padding
+    HIP_TRY(e, hipHostMalloc((void**)&s.h_out, out_max, hipHostMallocDefault));
+    HIP_TRY(e, hipMalloc((void**)&s.d_out, out_max));
+    HIP_TRY(e, hipMemset(s.d_out, 0, 64));
+    std::memset(s.h_out, 0, 64);
     HIP_TRY(e, hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -216,16 +211,10 @@ int alloc_slot(bk_engine* e, Slot& s) {
 
 void free_slot(Slot& s) {
     if (s.h_in) (void)hipHostFree(s.h_in);
-    if (s.h_logits) (void)hipHostFree(s.h_logits);
-    if (s.h_probs) (void)hipHostFree(s.h_probs);
-    if (s.h_values) (void)hipHostFree(s.h_values);
+    if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_pos) (void)hipFree(s.d_pos);
-    if (s.d_logits) (void)hipFree(s.d_logits);
-    if (s.d_probs) (void)hipFree(s.d_probs);
-    if (s.d_values) (void)hipFree(s.d_values);
-    if (s.d_flag) (void)hipFree(s.d_flag);
-    if (s.h_flag) (void)hipHostFree(s.h_flag);
+    if (s.d_out) (void)hipFree(s.d_out);
     if (s.in_ready) (void)hipEventDestroy(s.in_ready);
     if (s.computed) (void)hipEventDestroy(s.computed);
     if (s.done) (void)hipEventDestroy(s.done);
@@ -443,34 +432,44 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     HIP_TRY(e, hipSetDevice(e->device));
     const size_t bytes = (size_t)B * (src_kind == kSrcPositions ? (size_t)BK_POS_BYTES : src_kind == BK_FEATS_U8 ? 2187 : 2187 * 4);
     const int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
+    // small requests (the single-tree genmove regime) have nothing to overlap: everything goes on the compute
+    // stream and the two cross-stream event hops are saved; large ones use the three-stream chain
+    const bool chained = B > 256;
+    hipStream_t sin = chained ? e->s_in : e->stream, sout = chained ? e->s_out : e->stream;
     if (B > 0) {
         std::memcpy(s->h_in, src, bytes);
-        HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, e->s_in));
+        HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, sin));
         if (src_kind == kSrcPositions) {
-            // the encoder runs on the copy-in stream: small workgroups (2.8 KB LDS) that fit beside the
+            // chained: the encoder runs on the copy-in stream, small workgroups (3 KB LDS) that fit beside the
             // 3-board leaf workgroups of the previous request still running on the compute stream
-            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->s_in));
+            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             e->st.positions_encoded += (uint64_t)B;
         }
-        HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
-        *s->h_flag = 0;
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
-        if (e->precision == BK_PRECISION_F16X2) HIP_TRY(e, hipMemsetAsync(s->d_flag, 0, sizeof(unsigned int), e->stream));
-        rc = enqueue(e, s->d_in, dtype, B, n_policy, want, s->d_logits, s->d_probs, s->d_values, e->stream,
-                     e->precision, s->d_flag);
+        if (chained) {
+            HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
+        }
+        // output block of this request
+        s->off_values = 64;
+        s->off_probs = s->off_values + (((want & BK_WANT_VALUE) ? (size_t)B * 4 : 0) + 63) / 64 * 64;
+        s->off_logits = s->off_probs + (((want & BK_WANT_PROBS) ? (size_t)n_policy * 81 * 4 : 0) + 63) / 64 * 64;
+        s->out_bytes = s->off_logits + ((want & BK_WANT_LOGITS) ? (size_t)n_policy * 81 * 4 : 0);
+        unsigned int* d_flag = reinterpret_cast<unsigned int*>(s->d_out);
+        if (s->flag_dirty) {  // only after an overflow was seen: the flag is zero otherwise
+            HIP_TRY(e, hipMemsetAsync(d_flag, 0, sizeof(unsigned int), e->stream));
+            s->flag_dirty = false;
+        }
+        rc = enqueue(e, s->d_in, dtype, B, n_policy, want, reinterpret_cast<float*>(s->d_out + s->off_logits),
+                     reinterpret_cast<float*>(s->d_out + s->off_probs), reinterpret_cast<float*>(s->d_out + s->off_values),
+                     e->stream, e->precision, d_flag);
         if (rc) return rc;
-        HIP_TRY(e, hipEventRecord(s->computed, e->stream));
-        HIP_TRY(e, hipStreamWaitEvent(e->s_out, s->computed, 0));
-        if (e->precision == BK_PRECISION_F16X2)
-            HIP_TRY(e, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, e->s_out));
-        if ((want & BK_WANT_LOGITS) && n_policy)
-            HIP_TRY(e, hipMemcpyAsync(s->h_logits, s->d_logits, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->s_out));
-        if ((want & BK_WANT_PROBS) && n_policy)
-            HIP_TRY(e, hipMemcpyAsync(s->h_probs, s->d_probs, (size_t)n_policy * 81 * 4, hipMemcpyDeviceToHost, e->s_out));
-        if (want & BK_WANT_VALUE)
-            HIP_TRY(e, hipMemcpyAsync(s->h_values, s->d_values, (size_t)B * 4, hipMemcpyDeviceToHost, e->s_out));
+        if (chained) {
+            HIP_TRY(e, hipEventRecord(s->computed, e->stream));
+            HIP_TRY(e, hipStreamWaitEvent(e->s_out, s->computed, 0));
+        }
+        HIP_TRY(e, hipMemcpyAsync(s->h_out, s->d_out, s->out_bytes, hipMemcpyDeviceToHost, sout));  // flag + all outputs
     }
-    HIP_TRY(e, hipEventRecord(s->done, e->s_out));
+    HIP_TRY(e, hipEventRecord(s->done, sout));
     s->busy = true;
     s->ticket = e->next_ticket++;
     s->B = B;
@@ -526,24 +525,21 @@ int bk_wait(bk_engine* e, int64_t ticket) {
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
         HIP_TRY(e, hipEventSynchronize(s.done));
-        if (s.B > 0 && *s.h_flag) {
+        if (s.B > 0 && *reinterpret_cast<unsigned int*>(s.h_out)) {
             // the f16x2 kernel clamped an activation: redo this request on the exact fp32 kernel
             e->st.f16_overflow_fallbacks += 1;
-            int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, s.d_logits, s.d_probs, s.d_values, e->stream,
-                             BK_PRECISION_F32, nullptr);
+            s.flag_dirty = true;
+            int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, reinterpret_cast<float*>(s.d_out + s.off_logits),
+                             reinterpret_cast<float*>(s.d_out + s.off_probs), reinterpret_cast<float*>(s.d_out + s.off_values),
+                             e->stream, BK_PRECISION_F32, nullptr);
             if (rc) return rc;
-            if ((s.want & BK_WANT_LOGITS) && s.n_policy)
-                HIP_TRY(e, hipMemcpyAsync(s.h_logits, s.d_logits, (size_t)s.n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
-            if ((s.want & BK_WANT_PROBS) && s.n_policy)
-                HIP_TRY(e, hipMemcpyAsync(s.h_probs, s.d_probs, (size_t)s.n_policy * 81 * 4, hipMemcpyDeviceToHost, e->stream));
-            if (s.want & BK_WANT_VALUE)
-                HIP_TRY(e, hipMemcpyAsync(s.h_values, s.d_values, (size_t)s.B * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, s.out_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(e, hipStreamSynchronize(e->stream));
-            *s.h_flag = 0;
+            *reinterpret_cast<unsigned int*>(s.h_out) = 0;
         }
-        if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_logits, (size_t)s.n_policy * 81 * 4);
-        if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_probs, (size_t)s.n_policy * 81 * 4);
-        if (s.want & BK_WANT_VALUE) std::memcpy(s.values, s.h_values, (size_t)s.B * 4);
+        if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_out + s.off_logits, (size_t)s.n_policy * 81 * 4);
+        if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_out + s.off_probs, (size_t)s.n_policy * 81 * 4);
+        if (s.want & BK_WANT_VALUE) std::memcpy(s.values, s.h_out + s.off_values, (size_t)s.B * 4);
         s.busy = false;
         return BK_OK;
     }
