@@ -469,7 +469,7 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu) {
         const int v = atoi(f);
         if (v >= 1 && v <= 3) return v;
     }
-    const int mt[4] = {0, 3, 6, 8};
+    const int mt[4] = {0, 44, 77, 100};  // measured time of one round of 1/2/3-board workgroups (86 : 150 : 195 us)
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
