@@ -44,7 +44,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("evals", ctypes.c_uint64), ("batches", ctypes.c_uint64), ("max_batch_seen", ctypes.c_uint64),
                 ("kernel_ms_sum", ctypes.c_double), ("kernel_ms_count", ctypes.c_uint64),
                 ("last_kernel_ms", ctypes.c_double), ("f16_overflow_fallbacks", ctypes.c_uint64),
-                ("f16_device_overflow", ctypes.c_uint64), ("positions_encoded", ctypes.c_uint64)]
+                ("f16_device_overflow", ctypes.c_uint64), ("positions_encoded", ctypes.c_uint64),
+                ("split_launches", ctypes.c_uint64)]
 
 
 # every symbol include/bokego_amd.h declares: (restype, argtypes)

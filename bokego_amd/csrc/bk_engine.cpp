@@ -266,7 +266,6 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
 #ifdef BK_STAMPS
     a.stamps = e->d_stamps;
 #endif
-    const int nb = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
     bool timed = false;
     size_t slot = 0;
     if (e->profiling) {
@@ -279,8 +278,43 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         timed = true;
     }
     a.overflow = d_flag;
-    HIP_TRY(e, precision == BK_PRECISION_F16X2 ? bk_launch_leaf_eval_f16(a, nb, stream)
-                                              : bk_launch_leaf_eval(a, nb, stream));
+    auto launch = [&](const bk_eval_args& args, int nb) {
+        return precision == BK_PRECISION_F16X2 ? bk_launch_leaf_eval_f16(args, nb, stream) : bk_launch_leaf_eval(args, nb, stream);
+    };
+    // Launch plan: either one launch with the best single workgroup size, or k whole rounds of 3-board
+    // workgroups (one per CU) followed by a tail launch whose workgroup size makes the partial last round
+    // shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead of
+    // 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.
+    const int nb1 = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
+    long best = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu);
+    int head_p = 0, head_v = 0, tail_nb = 0;
+    const int full_p = a.B_policy / 3, full_v = a.B_value / 3;   // complete 3-board workgroups per net
+    if (!getenv("BK_FORCE_NB") && !getenv("BK_NO_SPLIT")) {
+        for (long k = 1; k * e->n_cu <= full_p + full_v; ++k) {
+            const long head = k * e->n_cu;
+            int hp = (int)std::min<long>(full_p, (head * full_p / (full_p + full_v)) & ~3L);  // keep the 4-block XCD pairing
+            int hv = (int)(head - hp);
+            if (hv > full_v) { hv = full_v; hp = (int)(head - hv); }
+            const int rp = a.B_policy - 3 * hp, rv = a.B_value - 3 * hv;
+            if (rp + rv == 0) break;
+            const int nbt = bk_pick_nb(rp, rv, e->n_cu);
+            const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, e->n_cu) + 4;  // + a second launch's overhead
+            if (cost < best) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }
+        }
+    }
+    if (tail_nb) {
+        bk_eval_args h = a;
+        h.B_policy = 3 * head_p;
+        h.B_value = 3 * head_v;
+        HIP_TRY(e, launch(h, 3));
+        bk_eval_args t = a;
+        t.off_p = 3 * head_p;
+        t.off_v = 3 * head_v;
+        HIP_TRY(e, launch(t, tail_nb));
+        e->st.split_launches += 1;
+    } else {
+        HIP_TRY(e, launch(a, nb1));
+    }
     if (timed) {
         HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
         e->ev_head = (e->ev_head + 1) % e->ev_ring.size();

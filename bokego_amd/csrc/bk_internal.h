@@ -46,6 +46,7 @@ struct bk_eval_args {
     int feats_dtype;
     int B_policy;          // PolicyNet runs on positions [0, B_policy)   (0: not at all)
     int B_value;           // ValueNet  runs on positions [0, B_value)
+    int off_p, off_v;      // this launch covers positions [off_p, B_policy) / [off_v, B_value) only
     int tasks_p, tasks_v;  // filled by the launcher: ceil(B_x / NB)
     float* logits;         // [B][81] or null
     float* probs;          // [B][81] or null
@@ -60,5 +61,6 @@ struct bk_eval_args {
 hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream);
 
 int bk_pick_nb(int B_policy, int B_value, int n_cu);
+long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu);  // modelled time of one launch (arbitrary units)
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
         else { net = 1; task = m4 + r - (a.tasks_p - m4); }
     }
     const bk_net_params& P = a.net[net];
-    const int b0 = task * NB;
+    const int b0 = (net ? a.off_v : a.off_p) + task * NB;  // this launch covers boards [off, B) of each net
     const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
     STAMP(0);
@@ -451,8 +451,8 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
         attr_set = true;
     }
     bk_eval_args args = a;
-    args.tasks_p = (a.B_policy + NB - 1) / NB;
-    args.tasks_v = (a.B_value + NB - 1) / NB;
+    args.tasks_p = (a.B_policy - a.off_p + NB - 1) / NB;
+    args.tasks_v = (a.B_value - a.off_v + NB - 1) / NB;
     const int grid = args.tasks_p + args.tasks_v;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Geo<NB>::LDS_BYTES, stream, args);
@@ -464,18 +464,22 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
 // Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is
 // (workgroup rounds over the CUs) x (32-row MFMA tiles per workgroup); NB=1 workgroups are small
 // enough (57 KB LDS) to sit two per CU but then share the pipes, so that buys nothing here.
+// measured time of one round (one workgroup per CU) of 1/2/3-board workgroups: 86 : 150 : 195 us
+long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu) {
+    static const int t[4] = {0, 44, 77, 100};
+    const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
+    return (wgs + n_cu - 1) / n_cu * t[nb];
+}
+
 int bk_pick_nb(int B_policy, int B_value, int n_cu) {
     if (const char* f = getenv("BK_FORCE_NB")) {
         const int v = atoi(f);
         if (v >= 1 && v <= 3) return v;
     }
-    const int mt[4] = {0, 44, 77, 100};  // measured time of one round of 1/2/3-board workgroups (86 : 150 : 195 us)
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
-        const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
-        const long rounds = (wgs + n_cu - 1) / n_cu;
-        const long cost = rounds * mt[nb];
+        const long cost = bk_launch_cost(B_policy, B_value, nb, n_cu);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
         else { net = 1; task = m4 + r - (a.tasks_p - m4); }
     }
     const bk_net_params& P = a.net[net];
-    const int b0 = task * NB;
+    const int b0 = (net ? a.off_v : a.off_p) + task * NB;  // this launch covers boards [off, B) of each net
     const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
     STAMP(0);
@@ -541,8 +541,8 @@ hipError_t launch16_nb(const bk_eval_args& a, hipStream_t stream) {
         attr_set = true;
     }
     bk_eval_args args = a;
-    args.tasks_p = (a.B_policy + NB - 1) / NB;
-    args.tasks_v = (a.B_value + NB - 1) / NB;
+    args.tasks_p = (a.B_policy - a.off_p + NB - 1) / NB;
+    args.tasks_v = (a.B_value - a.off_v + NB - 1) / NB;
     const int grid = args.tasks_p + args.tasks_v;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Geo<NB>::LDS_BYTES, stream, args);

@@ -90,6 +90,7 @@ typedef struct bk_stats_t {
     uint64_t f16_overflow_fallbacks; /* host-buffer requests redone in fp32 because an activation left the fp16 range */
     uint64_t f16_device_overflow;    /* bk_eval_device*: non-zero if that ever happened (results of that call unreliable) */
     uint64_t positions_encoded;      /* position records turned into feature planes on the GPU */
+    uint64_t split_launches;         /* evaluations run as whole rounds of 3-board workgroups + a shorter tail launch */
 } bk_stats_t;
 
 int bk_abi_version(void);

@@ -300,3 +300,29 @@ def test_random_weights_vs_oracle(gold, precision, seed, gain):
     assert np.abs(out["probs"] - pr).max() < TOL_PROB * 2
     assert np.abs(out["value"] - va).max() < TOL_VALUE
     assert np.isfinite(out["logits"]).all() and st["f16_overflow_fallbacks"] in (0, 1)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_split_launch_is_bit_identical(precision, monkeypatch):
+    """Mid-size batches run as whole rounds of 3-board workgroups + a tail launch with smaller workgroups
+    (bk_stats().split_launches); every output must be bit-identical to the single-launch result."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(1500, seed_base=90_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=2048, precision=precision)
+    outs = {}
+    for split in (True, False):
+        if not split:
+            monkeypatch.setenv("BK_NO_SPLIT", "1")
+        res = []
+        for B, npol in ((1500, 1500), (1500, 40), (1201, 0), (900, 900), (771, 3), (1000, 0)):
+            s0 = eng.stats()["split_launches"]
+            res.append(eng.eval(x[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol))
+            res[-1]["split"] = eng.stats()["split_launches"] - s0
+        outs[split] = res
+    assert sum(r["split"] for r in outs[True]) >= 3 and sum(r["split"] for r in outs[False]) == 0
+    for a, b in zip(outs[True], outs[False]):
+        for k in ("logits", "probs", "value"):
+            if k in b:
+                assert np.array_equal(a[k], b[k]), k
