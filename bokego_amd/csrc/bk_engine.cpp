@@ -286,7 +286,8 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead of
     // 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.
     const int nb1 = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
-    long best = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu);
+    const long single = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu);
+    long best = single;
     int head_p = 0, head_v = 0, tail_nb = 0;
     const int full_p = a.B_policy / 3, full_v = a.B_value / 3;   // complete 3-board workgroups per net
     if (!getenv("BK_FORCE_NB") && !getenv("BK_NO_SPLIT")) {
@@ -299,7 +300,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
             if (rp + rv == 0) break;
             const int nbt = bk_pick_nb(rp, rv, e->n_cu);
             const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, e->n_cu) + 4;  // + a second launch's overhead
-            if (cost < best) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }
+            if (cost < best && cost * 100 <= single * 97) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }  // worth >= 3 %
         }
     }
     if (tail_nb) {
