@@ -130,6 +130,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a one-GPU box: BK_BENCH_BACKEND=gloo BK_BENCH_DEVICE=0 lets several ranks
+    # share one card (RCCL refuses two ranks on one GPU); the numbers of such a run mean nothing
+    backend = os.environ.get("BK_BENCH_BACKEND", "nccl")
+    if "BK_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BK_BENCH_DEVICE"])
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
@@ -138,7 +144,10 @@ def main():
     if world > 1 or os.environ.get("BK_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from bokego_amd.bkw import load_bkw
     from bokego_amd.engine import LeafEngine
@@ -168,7 +177,7 @@ def main():
     s1 = eng.stats()
     eng.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])
@@ -228,10 +237,10 @@ def main():
         barrier()
         threads = max(1, min(16, len(os.sched_getaffinity(0)) // world))  # host cores are shared by the ranks
         local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
-                                          reduce_device=torch.device("cuda", local_rank))
+                                          reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
         secs = local["seconds"]
         if dist is not None:
-            t = torch.tensor([secs], dtype=torch.float64, device="cuda")
+            t = torch.tensor([secs], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             secs = float(t.item())
         sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus", "games": total["games"],
