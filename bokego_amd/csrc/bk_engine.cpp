@@ -52,7 +52,7 @@ struct bk_engine {
     int max_batch = 0;
     int n_cu = 256;
     bool has_policy = false, has_value = false;
-    int precision = BK_PRECISION_F16X2;
+    int precision = BK_PRECISION_F32;
     // ticket path: H2D, kernels and D2H run on three streams chained by per-slot events, so the copies of
     // one request overlap the kernel of another (MI355X has separate SDMA engines per direction)
     hipStream_t stream = nullptr;       // compute
@@ -67,7 +67,10 @@ struct bk_engine {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
     size_t ev_head = 0, ev_pending = 0;
-    unsigned int* d_dev_flag = nullptr;      // f16x2 overflow flag of the device-pointer path (sticky)
+    // device-pointer path, f16x2: [0] = sequence number of the last call whose f16x2 kernel overflowed (what gates that
+    // call's fp32 redo kernel), [1] = number of calls redone
+    unsigned int* d_dev_flag = nullptr;
+    unsigned int dev_seq = 0;
     unsigned long long* d_stamps = nullptr;  // diagnostic builds only
 };
 
@@ -249,8 +252,12 @@ void drain_events(bk_engine* e) {
 }
 
 // enqueue one kernel launch on `stream`; all pointers are device pointers
+// d_flag/tag: where and with what value the f16x2 kernel reports an activation outside the fp16 range.
+// gated_redo (device-pointer path, f16x2): the exact-fp32 kernel follows on the same stream with the same launch plan,
+// gated on d_flag[0] == tag -- stream-ordered, no host round trip, and a few microseconds when nothing overflowed.
 int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, int want, float* d_logits,
-            float* d_probs, float* d_values, hipStream_t stream, int precision, unsigned int* d_flag) {
+            float* d_probs, float* d_values, hipStream_t stream, int precision, unsigned int* d_flag,
+            unsigned int tag = 1, bool gated_redo = false) {
     if (B == 0) return BK_OK;
     bk_eval_args a{};
     a.net[0] = e->net[0];
@@ -278,8 +285,17 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         timed = true;
     }
     a.overflow = d_flag;
+    a.overflow_tag = tag;
+    gated_redo = gated_redo && precision == BK_PRECISION_F16X2 && d_flag;
     auto launch = [&](const bk_eval_args& args, int nb) {
-        return precision == BK_PRECISION_F16X2 ? bk_launch_leaf_eval_f16(args, nb, stream) : bk_launch_leaf_eval(args, nb, stream);
+        if (precision != BK_PRECISION_F16X2) return bk_launch_leaf_eval(args, nb, stream);
+        hipError_t rc = bk_launch_leaf_eval_f16(args, nb, stream);
+        if (rc != hipSuccess || !gated_redo) return rc;
+        bk_eval_args r = args;
+        r.overflow = nullptr;
+        r.gate = d_flag;
+        r.gate_tag = tag;
+        return bk_launch_leaf_eval(r, nb, stream);
     };
     // Launch plan: either one launch with the best single workgroup size, or k whole rounds of 3-board
     // workgroups (one per CU) followed by a tail launch whose workgroup size makes the partial last round
@@ -363,8 +379,8 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->max_batch = max_batch;
     e->has_policy = policy != nullptr;
     e->has_value = value != nullptr;
-    e->precision = BK_PRECISION_F16X2;  // default: fast path with automatic fp32 fallback on overflow
-    if (const char* pz = getenv("BK_PRECISION")) e->precision = std::string(pz) == "f32" ? BK_PRECISION_F32 : BK_PRECISION_F16X2;
+    e->precision = BK_PRECISION_F32;  // default: the reference's arithmetic width (torch fp32); f16x2 is opt-in
+    if (const char* pz = getenv("BK_PRECISION")) e->precision = std::string(pz) == "f16x2" ? BK_PRECISION_F16X2 : BK_PRECISION_F32;
     int rc = BK_OK;
     auto bail = [&](int code) {
         g_create_error = e->err;
@@ -416,9 +432,9 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
     e->dev_allocs.push_back(e->d_stamps);
 #endif
-    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, sizeof(unsigned int)));
+    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, 2 * sizeof(unsigned int)));
     e->dev_allocs.push_back(e->d_dev_flag);
-    TRY_CREATE(hipMemset(e->d_dev_flag, 0, sizeof(unsigned int)));
+    TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);
     e->ev_ring.resize(512);
@@ -615,8 +631,9 @@ int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, in
     HIP_TRY(e, hipSetDevice(e->device));
     // `stream` is used as given: NULL is HIP's null (legacy default) stream, which is also what
     // torch.cuda.current_stream() is unless the caller switched streams.
+    if (++e->dev_seq == 0) e->dev_seq = 1;  // 2^32 calls later a stale tag could match: skip 0, the flag's reset value
     return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
-                   static_cast<hipStream_t>(stream), e->precision, e->d_dev_flag);
+                   static_cast<hipStream_t>(stream), e->precision, e->d_dev_flag, e->dev_seq, true);
 }
 
 int bk_engine_set_precision(bk_engine* e, int precision) {
@@ -649,11 +666,12 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
         HIP_TRY(e, hipDeviceSynchronize());
         drain_events(e);
     }
-    if (e->d_dev_flag) {  // sticky flag of bk_eval_device*: the caller decides what to do about it
-        unsigned int f = 0;
+    if (e->d_dev_flag && e->dev_seq) {  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
+        unsigned int f[2] = {0, 0};
         HIP_TRY(e, hipSetDevice(e->device));
-        HIP_TRY(e, hipMemcpy(&f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
-        e->st.f16_device_overflow = f;
+        HIP_TRY(e, hipDeviceSynchronize());  // the calls may sit on any caller stream
+        HIP_TRY(e, hipMemcpy(f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
+        e->st.f16_device_overflow = f[1];
     }
     *out = e->st;
     return BK_OK;

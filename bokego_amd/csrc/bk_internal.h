@@ -51,7 +51,12 @@ struct bk_eval_args {
     float* logits;         // [B][81] or null
     float* probs;          // [B][81] or null
     float* values;         // [B] or null
-    unsigned int* overflow;      // f16x2: set to 1 if an activation left the fp16 range (result unreliable)
+    unsigned int* overflow;      // f16x2: raised to overflow_tag (atomicMax) if an activation left the fp16 range
+    unsigned int overflow_tag;   //   (result unreliable); host-buffer path: 1, device-pointer path: the call's sequence number
+    // exact-fp32 kernel launched as the REDO of an f16x2 call on the device-pointer path: every workgroup returns at
+    // once unless gate[0] == gate_tag (the f16x2 kernel of the same call raised the flag); gate[1] counts redone calls
+    unsigned int* gate;
+    unsigned int gate_tag;
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 

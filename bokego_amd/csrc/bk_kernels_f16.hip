@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_f16_kernel(const bk_eval_arg
     }
 
     // an activation beyond the fp16 range was clamped: tell the host, which re-runs the batch in fp32
-    if (__any(!(umax < 65504.f)) && lane == 0 && a.overflow) atomicOr(a.overflow, 1u);
+    if (__any(!(umax < 65504.f)) && lane == 0 && a.overflow) atomicMax(a.overflow, a.overflow_tag);
 
     // ---- heads.  1x1 conv (untied bias): one thread per board point over all 4 waves, results to LDS;
     //      then wave w finishes board w (activations = (hi + lo) * inv_sa) ----

@@ -43,6 +43,7 @@ class _GTPProtocol:
         self._move_history = []
         self._last_root = None
         self._undid = False
+        self._komi = None          # set by the `komi` command; re-applied to every root installed afterwards
         self.genmove_seconds = []
 
     # ---- main loop ---------------------------------------------------------------------------------
@@ -81,6 +82,8 @@ class _GTPProtocol:
         if name not in self.commands:
             ok, text = False, f"unknown command '{name}'"
         else:
+            if self._komi is not None:       # roots installed by moves / search since the last command: same komi
+                self._set_komi(self._komi)
             res = getattr(self, "_c_" + name)(args, self.root.turn)
             if not isinstance(res, tuple):
                 return res                      # analyze: a generator of info lines
@@ -117,17 +120,33 @@ class _GTPProtocol:
         return True, ""
 
     def _c_clear_board(self, args, turn):
-        self.set_root(self._node())
+        self._install_root(self._node(), keep_komi=False)
         return True, ""
 
     def _c_komi(self, args, turn):
         if not args:
             return False, "usage: komi <num-komi>"
         try:
-            self.root.komi = float(args[0])
+            self._set_komi(float(args[0]))
         except ValueError:
             return False, "invalid komi value"
         return True, ""
+
+    def _set_komi(self, komi):
+        """The reference writes `self.root.komi` (gtp.py:151-159) and loses it at the next move, because Go_MCTS
+        nodes are rebuilt with the default (mcts.py:275-277).  Here the value stays in force for final_score /
+        printsgf across moves, undo and handicap roots; `clear_board` resets it to 5.5 exactly as the reference's
+        set_root(Go_MCTS()) does (gtp.py:147-149; pinned by tests/golden/gtp_transcript.json)."""
+        self._komi = komi
+        self.root.komi = komi
+
+    def _install_root(self, node, keep_komi=True):
+        self.set_root(node)
+        if not keep_komi:
+            self._set_komi(5.5)        # the tree may hand back an interned node that still carries the old value
+            self._komi = None
+        elif self._komi is not None:
+            self._set_komi(self._komi)
 
     def _c_play(self, args, turn):
         if len(args) < 2 or args[0] not in self.colors:
@@ -175,7 +194,7 @@ class _GTPProtocol:
     def _c_undo(self, args, turn):
         if self._undid or self._last_root is None:     # one level only, like the reference
             return False, "cannot undo"
-        self.set_root(self._last_root)
+        self._install_root(self._last_root)
         self._move_history.pop()
         self._last_root, self._undid = None, True
         return True, ""
@@ -213,7 +232,7 @@ class _GTPProtocol:
         if not 1 < n <= 5:
             return False, "invalid number of handicaps"
         stones = FLOWERS9[:n]
-        self.set_root(self._node(board="".join(go.BLACK if i in stones else go.EMPTY for i in range(81)), turn=1))
+        self._install_root(self._node(board="".join(go.BLACK if i in stones else go.EMPTY for i in range(81)), turn=1))
         return True, " ".join(go.unsquash(list(stones)))
 
     def _c_printsgf(self, args, turn):
@@ -251,7 +270,7 @@ class _GTPProtocol:
     def input_move(self, sq_c):
         node = self.root.make_move(sq_c)
         self._last_root = self.root
-        self.set_root(node)
+        self._install_root(node)
         self._move_history.append(sq_c)
         self._undid = False
 
@@ -310,6 +329,10 @@ class NativeGTP(_GTPProtocol, NativeMCTS):
     """Same protocol on the native tree core: ~10x less host time per genmove."""
     _node = Position
 
+    def _set_komi(self, komi):
+        # NativeMCTS.root is a fresh snapshot on every access: the komi lives on the tree
+        self._komi = self.komi = komi
+
 
 def load_state_dict(path):
     """A reference checkpoint ({"model_state_dict": ...}, boke.py:31-37), a bare state_dict, or a BKW1 file."""
@@ -329,17 +352,17 @@ def main(argv=None):
     ap.add_argument("-p", metavar="PATH", default=os.path.join(golden, "policy_19.bkw"), help="policy weights (.pt/.bkw)")
     ap.add_argument("-v", metavar="PATH", default=os.path.join(golden, "value_synth.bkw"), help="value weights (.pt/.bkw)")
     ap.add_argument("-g", "--gpu", type=int, default=0, help="GPU index")
-    ap.add_argument("--precision", choices=["f16x2", "f32"], default=None)
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
+                    help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     ap.add_argument("--ponder", action="store_true")
     ap.add_argument("--python-tree", action="store_true", help="search with the Python tree (needed for `analyze`)")
     args = ap.parse_args(argv)
 
     from . import nnet
-    pi, val = nnet.HipPolicyNet(load_state_dict(args.p), device_id=args.gpu), nnet.HipValueNet(load_state_dict(args.v), device_id=args.gpu)
+    pi = nnet.HipPolicyNet(load_state_dict(args.p), device_id=args.gpu, precision=args.precision)
+    val = nnet.HipValueNet(load_state_dict(args.v), device_id=args.gpu, precision=args.precision)
     cls, root = (GTP, Go_MCTS()) if args.python_tree else (NativeGTP, Position())
     gtp = cls(root, pi, val, no_sim=True, time_lim=None if args.r else args.t, n_rollouts=args.r, pondering=args.ponder)
-    if args.precision:
-        gtp.evaluator.engine.set_precision(args.precision)
     gtp.start()
 
 

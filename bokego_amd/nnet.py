@@ -34,7 +34,10 @@ class _HipNet:
     _names = _TRUNK_NAMES
     _is_value = False
 
-    def __init__(self, state_dict=None, device_id=0, max_batch=1024):
+    def __init__(self, state_dict=None, device_id=0, max_batch=1024, precision=None):
+        """precision: None = the engine default ('f32', the reference's arithmetic width; env BK_PRECISION
+        overrides) or 'f16x2' (opt-in split-fp16 fast path, see include/bokego_amd.h)."""
+        self.precision = precision
         self._sd = None
         self._engine = None
         self._shared = False
@@ -109,7 +112,7 @@ class _HipNet:
         if self._engine is None:
             self._need_weights()
             kw = {"value_sd" if self._is_value else "policy_sd": self._sd}
-            self._engine = LeafEngine(device_id=self.device_id, max_batch=self.max_batch, **kw)
+            self._engine = LeafEngine(device_id=self.device_id, max_batch=self.max_batch, precision=self.precision, **kw)
         return self._engine
 
     def _run(self, x, **want):
@@ -165,7 +168,7 @@ class HipValueNet(_HipNet):
         return self.load_state_dict(new)
 
 
-def fuse(policy_net, value_net, max_batch=None):
+def fuse(policy_net, value_net, max_batch=None, precision=None):
     """Put a HipPolicyNet and a HipValueNet on ONE engine so a batch needs one kernel launch.
     Returns the shared LeafEngine (also what the batched MCTS uses)."""
     if not isinstance(policy_net, HipPolicyNet) or not isinstance(value_net, HipValueNet):
@@ -175,7 +178,8 @@ def fuse(policy_net, value_net, max_batch=None):
     policy_net._need_weights()
     value_net._need_weights()
     mb = int(max_batch or max(policy_net.max_batch, value_net.max_batch))
-    eng = LeafEngine(policy_net._sd, value_net._sd, device_id=policy_net.device_id, max_batch=mb)
+    eng = LeafEngine(policy_net._sd, value_net._sd, device_id=policy_net.device_id, max_batch=mb,
+                     precision=precision or policy_net.precision or value_net.precision)
     for n in (policy_net, value_net):
         n._drop_engine()
         n._engine, n._shared, n.max_batch, n.device_id = eng, True, mb, policy_net.device_id

@@ -88,7 +88,7 @@ typedef struct bk_stats_t {
     uint64_t kernel_ms_count;
     double last_kernel_ms;
     uint64_t f16_overflow_fallbacks; /* host-buffer requests redone in fp32 because an activation left the fp16 range */
-    uint64_t f16_device_overflow;    /* bk_eval_device*: non-zero if that ever happened (results of that call unreliable) */
+    uint64_t f16_device_overflow;    /* bk_eval_device* calls redone in fp32 (gated launch on the caller's stream) for the same reason */
     uint64_t positions_encoded;      /* position records turned into feature planes on the GPU */
     uint64_t split_launches;         /* evaluations run as whole rounds of 3-board workgroups + a shorter tail launch */
 } bk_stats_t;
@@ -160,14 +160,18 @@ int64_t bk_submit_positions(bk_engine *e, const void *positions, int B, int n_po
 int bk_encode_positions(bk_engine *e, const void *positions, int B, uint8_t *planes);
 
 /*
- * Arithmetic of the conv stacks (new; the reference computes in torch fp32):
- *   BK_PRECISION_FP32   v_mfma_f32_32x32x2_f32, exact fp32 products and fp32 accumulation
- *   BK_PRECISION_F16X2  (default) every operand split into an fp16 hi/lo pair (22 significant bits),
- *                       three v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation; ~fp32 accuracy
- *                       (inside the 1e-4 parity budget), several times the throughput.  If an
- *                       activation leaves the fp16 range (|x| >= 4094) the kernel raises a flag
- *                       and bk_wait() transparently redoes that request on the fp32 kernel;
- *                       bk_eval_device* only records it in bk_stats().f16_device_overflow.
+ * Arithmetic of the conv stacks (new; the reference computes in torch fp32, nnet.py:31-57,73-113):
+ *   BK_PRECISION_FP32   (default) v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation -- the
+ *                       reference's arithmetic width
+ *   BK_PRECISION_F16X2  opt-in: every operand split into an fp16 hi/lo pair (22 significant bits), three
+ *                       v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation; measured as close to a float64
+ *                       evaluation of the reference as the fp32 kernel is, ~4x the throughput.
+ *                       If an activation leaves the fp16 range (|x| >= 4094) the kernel raises a flag and the
+ *                       request is redone on the fp32 kernel: by bk_wait() for host-buffer requests
+ *                       (bk_stats().f16_overflow_fallbacks), and for bk_eval_device* by an fp32 launch enqueued
+ *                       behind the f16x2 one on the caller's stream that is a no-op unless the flag was raised
+ *                       (bk_stats().f16_device_overflow counts the calls redone).  Either way the caller never
+ *                       sees a clamped result.
  * The environment variable BK_PRECISION=f32|f16x2 sets the default of new engines.
  */
 #define BK_PRECISION_FP32 0

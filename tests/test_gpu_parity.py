@@ -171,6 +171,50 @@ def test_f16x2_overflow_falls_back_to_fp32(weights, oracle):
     fast.close(); exact.close()
 
 
+def test_f16x2_overflow_on_the_device_path_is_redone_in_fp32(weights, gold):
+    """bk_eval_device* (LeafEngine.eval_device, HipPolicyNet/HipValueNet on CUDA tensors): an f16x2 call whose
+    kernel overflows is redone by the gated fp32 launch enqueued behind it on the caller's stream -- the
+    caller gets bit-identical fp32 results, never the clamped ones, with no host round trip; the calls
+    before and after it stay on the f16x2 kernel."""
+    import torch
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.nnet import HipPolicyNet, HipValueNet
+    rng = np.random.default_rng(3)
+    big = (rng.integers(0, 8, size=(700, 27, 9, 9)) * 4000.0).astype(np.float32)
+    sane = gold[0][:700].astype(np.float32)
+    sane[:5] = big[:5] / 4000.0
+    fast = LeafEngine(weights[0], weights[1], max_batch=1024, precision="f16x2")
+    exact = LeafEngine(weights[0], weights[1], max_batch=1024, precision="f32")
+    side = torch.cuda.Stream()
+    for stream in (None, side):          # torch's current stream, and an explicit non-default one
+        with torch.cuda.stream(side) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            n0 = fast.stats()["f16_device_overflow"]
+            xs, xb = torch.from_numpy(sane).cuda(), torch.from_numpy(big).cuda()
+            a0 = fast.eval_device(xs, logits=True, probs=True, value=True)
+            a1 = fast.eval_device(xb, logits=True, probs=True, value=True, n_policy=333)   # split-launch sized
+            a2 = fast.eval_device(xs, logits=True, probs=True, value=True)
+            b1 = exact.eval_device(xb, logits=True, probs=True, value=True, n_policy=333)
+            f0 = fast.eval(sane, logits=True, probs=True, value=True)
+            torch.cuda.synchronize()
+            for k in ("logits", "probs", "value"):
+                assert torch.equal(a1[k], b1[k]), k                      # redone: the fp32 kernel's bits
+                assert torch.equal(a0[k], a2[k]), k                      # neighbours untouched ...
+                assert np.array_equal(a0[k].cpu().numpy(), f0[k]), k     # ... and still the f16x2 kernel's bits
+            assert torch.isfinite(a1["logits"]).all()
+            assert fast.stats()["f16_device_overflow"] == n0 + 1 and exact.stats()["f16_device_overflow"] == 0
+    # the drop-in nets on CUDA tensors go through the same path
+    pn, vn = HipPolicyNet(weights[0], max_batch=64, precision="f16x2"), HipValueNet(weights[1], max_batch=64, precision="f16x2")
+    assert pn.engine().precision == "f16x2" and HipPolicyNet(weights[0]).engine().precision == "f32"   # f32 is the default
+    xb = torch.from_numpy(big[:5]).cuda()
+    lg, va = pn(xb), vn(xb)
+    torch.cuda.synchronize()
+    ref = exact.eval(big[:5], logits=True, probs=False, value=True)
+    assert lg.is_cuda and np.array_equal(lg.cpu().numpy(), ref["logits"])
+    assert np.array_equal(va.cpu().numpy().reshape(-1), ref["value"])
+    assert pn.engine().stats()["f16_device_overflow"] == 1 and vn.engine().stats()["f16_device_overflow"] == 1
+    fast.close(); exact.close()
+
+
 def test_abi_edge_cases(weights, gold):
     """Empty batch, max batch, argument errors through the raw C ABI."""
     import ctypes

@@ -52,3 +52,36 @@ def test_stdin_loop_and_clear_cache(nets):
     assert lines[0] == "= boke" and lines[1] == "=3 " and lines[2] == "= " and lines[3].startswith("= ")
     assert lines[4].startswith("= ") and lines[5] == "= " and len(lines) == 7   # nothing after quit
     assert len(g.genmove_seconds) == 1
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_komi_command_stays_in_force(nets, native, tmp_path):
+    """`komi` must reach final_score and printsgf on BOTH trees (the native tree's root is a snapshot, so the value
+    lives on the tree) and survive moves, genmove and handicap roots; clear_board resets it (reference transcript)."""
+    from bokego_amd.gtp import NativeGTP
+    from bokego_amd.mcts_native import Position
+    cls, root = (NativeGTP, Position()) if native else (GTP, Go_MCTS())
+    g = cls(root, nets[0], nets[1], no_sim=True, time_lim=None, n_rollouts=12, expand_thresh=3)
+    g.running = True
+
+    def score():
+        r = g.send("final_score").strip("= \n")
+        return 0.0 if r == "0" else float(r[2:]) * (1 if r[0] == "B" else -1)
+
+    assert score() == -5.5
+    assert g.send("komi 7.5") == "= \n\n" and score() == -7.5
+    assert g.send("play b e5") == "= \n\n" and score() == 81 - 7.5      # a lone stone owns the board (go.py:200-218)
+    assert g.send("genmove w").startswith("= ")
+    s75 = score()
+    sgf = tmp_path / "k.sgf"
+    g.send(f"printsgf {sgf}")
+    assert "KM[7.5]" in sgf.read_text()
+    assert g.send("komi 5.5") == "= \n\n" and score() == s75 + 2.0      # same position, komi 2 points lower
+    assert g.send("komi 7.5") == "= \n\n" and g.send("undo") == "= \n\n" and score() == 81 - 7.5
+    assert g.send("clear_board") == "= \n\n" and score() == -5.5        # reset, as in the reference
+    assert g.send("komi 7.5") == "= \n\n"
+    assert g.send("set_fixed_handicap 2").startswith("= ") and score() == 81 - 7.5
+    assert g.send("komi 0.5") == "= \n\n" and score() == 80.5
+    assert g.send("komi x") == "? invalid komi value\n\n"
+    if native:
+        g.close()
