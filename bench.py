@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- leaf-evals/s of the fused PolicyNet+ValueNet HIP engine on MI355X.
 
-A "step" is one pass of the hot path over one batch: BASELINE.json configs[1], 4096 9x9
-positions, policy logits + softmax + value, inputs already resident in HBM.  With --gpus N
-(launched through torch.distributed.run, one rank per GPU) every rank evaluates its own 4096
-positions per step: the path shards with no data-path collective ("weak" scaling).
+A "step" is one pass of the hot path over one batch: BASELINE.json configs[1], 4096 9x9 positions, policy
+logits + softmax + value, inputs already resident in HBM.  With --gpus N (launched through
+torch.distributed.run, one rank per GPU) every rank evaluates its own 4096 positions per step: the path shards
+with no data-path collective ("weak" scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline      bound = MFMA: SURVEY 8d's 266,838,272 algorithmic FLOP per leaf-eval over the dense MFMA
-                peak of the dtype the matrix unit executes (2,500 TFLOP/s for the default f16x2 kernel,
-                157.3 for --precision f32); kernel time from HIP events on the launch stream
-  cpu_baseline  the CPU oracle (oracle/nnet_ref.c, a port of the reference's forward pass) timed on this
-                host's cores on a bounded sample of the same workload
-  selfplay      secondary, outside the timed region: BASELINE configs[3] (512 self-play games sharded over
-                the ranks + the end-of-generation all-reduce) with its own CPU baseline at N=1.
+The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the reference's arithmetic width
+(torch fp32, bokego/nnet.py:31-57,73-113) -- timed over exactly --steps launches between barriers.  Beside it:
+  sustained     the same launches looped for >= 2 s (DVFS / power settle), reported next to the --steps figure
+  parity        measured IN THIS RUN on the timed engine through the timed entry point: max |dlogit| / |dprob| /
+                |dvalue| against the reference's recorded outputs for the 536 golden positions, plus a sample of
+                the timed workload against the CPU oracle
+  f16x2         the opt-in split-fp16 variant, same measurements, priced against the f16 MFMA peak
+  roofline      bound = MFMA: SURVEY 8d's 266,838,272 algorithmic FLOP per leaf-eval over the dense MFMA peak of the
+                dtype the matrix unit executes; kernel time from HIP events on the launch stream
+  cpu_baseline  the reference's CPU path restated (oracle/torch_ref.py: the same torch ops on the host's cores, and
+                oracle/nnet_ref.c, the plain-C port) on a bounded sample of the same workload
+  selfplay      secondary, outside the timed region: BASELINE configs[3] (512 self-play games sharded over the
+                ranks + the end-of-generation all-reduce), per precision, with a CPU baseline at N=1.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +38,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md chip table (dense, fp
 PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md chip table (dense f16/bf16 MFMA)
 BYTES_PER_LEAF = 8748 + 328          # compulsory HBM bytes (f32 planes in, 81 probs + value out)
 BATCH = 4096
+TOL = {"logit": 1e-4, "prob": 1e-5, "value": 1e-4}   # BASELINE.json north_star / SURVEY 8d config 1
+KERNEL = {"f32": "bk_leaf_eval_kernel<3, false>", "f16x2": "bk_leaf_eval_f16_kernel<3>"}
+DTYPE = {"f32": "f32", "f16x2": "f16x2 (fp16 hi/lo split operands = 22-bit significands, fp32 accumulate)"}
 
 
 def make_workload(B, rank):
@@ -42,19 +52,21 @@ def make_workload(B, rank):
     return make_batch(B, seed_base=20260 + rank * B, dtype=np.float32, with_records=True)
 
 
-def measured_traffic(batch):
-    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json,
-    produced by tools/profile_bench.sh + tools/summarize_prof.py); None if absent or another batch."""
+def measured_traffic(batch, precision):
+    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary of this kernel
+    (profiles/*_pmc_<precision>.json, produced by tools/profile_bench.sh + tools/summarize_prof.py).  Read from a
+    file, so it describes the commit that file was made at, not this run: the source is named beside it."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_pmc_{precision}.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
     if d.get("batch") != batch:
         return None, None
-    return d.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
+    return d.get("hbm_traffic_bytes_per_launch"), f"from_file:profiles/{os.path.basename(files[-1])} (batch {d.get('batch')})"
 
 
+# ---- host CPU description -------------------------------------------------------------------------------------------
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -65,65 +77,201 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pw, vw, x, target_s=12.0):
+def usable_cores():
+    """(threads this process may run on, cgroup CPU quota or None, physical cores among them)."""
+    visible = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len(sib.replace("-", ",").split(",")))
+    except OSError:
+        pass
+    physical = max(1, visible // smt)
+    return visible, quota, physical
+
+
+def cpu_baseline(pw, vw, x, budget_s=20.0):
+    """The reference's CPU path on this host, bounded to ~budget_s: (a) oracle/torch_ref.py -- the reference's own
+    operators on torch CPU -- at B = 1 / 64 / 4096 with every usable physical core and with 1 thread (SURVEY 8d,
+    BASELINE.md 4); (b) the plain-C port oracle/nnet_ref.c.  `value` = the fastest of them."""
+    import torch
     from oracle.oracle import OraclePolicy, OracleValue, set_threads
+    from oracle.torch_ref import TorchPolicy, TorchValue, leaf_eval
 
-    P, V = OraclePolicy(pw), OracleValue(vw)
-    # single thread first: one position at a time, and a 64-position batch
+    visible, quota, physical = usable_cores()
+    # a 1-GPU box gets a 16-CPU share of the host: more threads than that only fight over it
+    cores = int(os.environ.get("BK_CPU_THREADS", min(physical, quota or physical, 16 if quota is None and visible > 64 else physical)))
+    P, V = TorchPolicy(pw), TorchValue(vw)
+    xt = torch.from_numpy(x)
+    old = torch.get_num_threads()
+    t_all = time.perf_counter()
+
+    def rate(B, reps, min_s):
+        xb = xt[:B]
+        leaf_eval(P, V, xb)
+        n, t0 = 0, time.perf_counter()
+        while n < reps or time.perf_counter() - t0 < min_s:
+            leaf_eval(P, V, xb)
+            n += 1
+        return n * B / (time.perf_counter() - t0)
+
+    res = {}
+    for label, nthreads in (("all_cores", cores), ("one_thread", 1)):
+        torch.set_num_threads(nthreads)
+        res[label] = {"threads": nthreads, "B1": rate(1, 10, 0.5), "B64": rate(64, 2, 1.0 if nthreads > 1 else 0.5)}
+        if nthreads > 1:
+            res[label][f"B{len(x)}"] = rate(len(x), 1, min(4.0, budget_s / 4))
+    torch.set_num_threads(old)
+    # plain-C port: whole passes over the batch with the same number of threads, and one thread at B=64
+    Pc, Vc = OraclePolicy(pw), OracleValue(vw)
     set_threads(1)
-    P(x[:1]); V(x[:1])
-    t0 = time.time()
-    for i in range(8):
-        P(x[i:i + 1]); V(x[i:i + 1])
-    b1_ms = (time.time() - t0) / 8 * 1e3
-    t0 = time.time(); P(x[:64]); V(x[:64]); one_thread = 64 / (time.time() - t0)
-    # a 1-GPU box gets a 16-core share of the host (more threads only fight over them)
-    cores = set_threads(int(os.environ.get("BK_CPU_THREADS", min(16, len(os.sched_getaffinity(0))))))
-    n = 64
-    t0 = time.time(); P(x[:n]); V(x[:n]); dt = time.time() - t0  # warm + calibrate
-    reps = int(max(1, min(8, target_s / max(dt * len(x) / n, 1e-3))))   # whole passes over the batch, ~target_s
-    t0 = time.time()
-    for _ in range(reps):
-        P(x); V(x)
-    dt = time.time() - t0
-    return {"value": reps * len(x) / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} passes over the same {len(x)}-position batch, oracle/nnet_ref.c (OpenMP, fp32), {dt:.1f}s",
-            "cpu_model": cpu_model(), "host_cpus_visible": len(os.sched_getaffinity(0)),
-            "one_thread_leaf_evals_per_s": one_thread, "one_thread_batch1_ms_per_leaf_eval": b1_ms}
+    t0 = time.perf_counter(); Pc(x[:64]); Vc(x[:64]); c_one = 64 / (time.perf_counter() - t0)
+    set_threads(cores)
+    Pc(x[:256]); Vc(x[:256])
+    n = min(len(x), 2048)
+    t0 = time.perf_counter(); Pc(x[:n]); Vc(x[:n]); c_all = n / (time.perf_counter() - t0)
+    torch_best = max(v for k, v in res["all_cores"].items() if k.startswith("B"))
+    best = max(torch_best, c_all)
+    return {"value": best, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+            "which": "oracle/torch_ref.py (the reference's torch ops, oneDNN/MKL)" if torch_best >= c_all else "oracle/nnet_ref.c (plain C, OpenMP)",
+            "sample": f"same workload batch: torch CPU at B=1/64/{len(x)} with {cores} threads and B=1/64 with 1 thread, "
+                      f"C port {n} positions with {cores} threads and 64 with 1; {time.perf_counter() - t_all:.1f}s of CPU work",
+            "cpu_model": cpu_model(), "host_cpus_visible": visible, "cgroup_cpu_quota": quota, "physical_cores_visible": physical,
+            "torch_cpu_leaf_evals_per_s": res, "torch_threads_default": old,
+            "c_port_leaf_evals_per_s": {"threads": cores, "all_cores": c_all, "one_thread_B64": c_one}}
 
 
-def selfplay_cpu_baseline(pw, vw, plies_per_game, moves=3, rollouts=400, cores=16):
-    """The reference's way of running config 4 on the host: one sequential tree per process, one position per
-    network call (oracle/mcts_ref.py + the C oracle nets, 1 thread).  Bounded sample: `moves` moves of one
-    game; games/min is extrapolated to `cores` independent single-thread games."""
-    from oracle import oracle
-    from oracle.mcts_ref import RefMCTS
-    oracle.set_threads(1)
-    P, V = oracle.OraclePolicy(pw), oracle.OracleValue(vw)
+def selfplay_cpu_baseline(cores, rollouts=400):
+    """The reference's way of running configs[3] on the host: one sequential tree per process, one position per
+    network call (oracle/mcts_ref.py + oracle/torch_ref.py, 1 thread each).  `cores` worker processes play ONE FULL
+    GAME each, concurrently (fresh interpreters that never touch the GPU); games/min = games / slowest worker."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=REPO)
     t0 = time.perf_counter()
-    m = RefMCTS(lambda f: P(f), lambda f: V(f))
-    for _ in range(moves):
-        m.rollout(rollouts)
-        m.choose()
-    s_per_move = (time.perf_counter() - t0) / moves
-    cores = min(cores, len(os.sched_getaffinity(0)))
-    oracle.set_threads(cores)
-    return {"games_per_min": 60.0 / (plies_per_game * s_per_move) * cores, "unit": "games/min", "cores": cores, "kind": "port",
-            "s_per_move_one_core": s_per_move,
-            "sample": f"{moves} moves x {rollouts} rollouts of one sequential tree on 1 core (batch-1 network calls), "
-                      f"extrapolated to {plies_per_game:.0f} plies/game and {cores} independent games"}
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.mcts_ref", "--seed", str(s), "--rollouts", str(rollouts)],
+                              cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for s in range(cores)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        except Exception:  # noqa: BLE001  (a worker that fails only shrinks the sample)
+            p.kill()
+    wall = time.perf_counter() - t0
+    if not outs:
+        return None
+    return {"games_per_min": len(outs) / wall * 60.0, "unit": "games/min", "cores": cores, "kind": "port",
+            "games": len(outs), "wall_s": wall, "mean_plies": float(np.mean([o["plies"] for o in outs])),
+            "mean_s_per_move_one_core": float(np.mean([o["seconds"] / max(1, o["plies"]) for o in outs])),
+            "sample": f"{len(outs)} full games x {rollouts} rollouts/move, one sequential tree per process on one core each "
+                      f"(batch-1 torch-CPU network calls, as the reference makes them), run concurrently"}
+
+
+# ---- GPU measurements ---------------------------------------------------------------------------------------------------
+def parity_in_run(eng, torch):
+    """max |dlogit| / |dprob| / |dvalue| of THIS engine, through the timed entry point (eval_device), against the
+    reference's recorded outputs for the 536 golden positions (tests/golden/nets.npz, made by tools/gen_golden.py)."""
+    g = os.path.join(REPO, "tests", "golden")
+    f = np.load(os.path.join(g, "features.npz"))["incremental"].astype(np.float32)
+    n = np.load(os.path.join(g, "nets.npz"))
+    o = eng.eval_device(torch.from_numpy(f).cuda(), logits=True, probs=True, value=True)
+    torch.cuda.synchronize()
+    d = {"logit": float(np.abs(o["logits"].cpu().numpy() - n["logits_b1"]).max()),
+         "prob": float(np.abs(o["probs"].cpu().numpy() - n["probs_b1"]).max()),
+         "value": float(np.abs(o["value"].cpu().numpy() - n["values_b1"]).max())}
+    for k, v in d.items():
+        if not v < TOL[k]:
+            raise AssertionError(f"parity lost: max |d{k}| = {v:g} >= {TOL[k]:g} on the golden positions")
+    return {"positions": len(f), "max_abs_dlogit": d["logit"], "max_abs_dprob": d["prob"], "max_abs_dvalue": d["value"],
+            "tolerance": TOL, "against": "reference outputs recorded in tests/golden/nets.npz"}
+
+
+def measure(eng, x, steps, warmup, barrier, reduce_max, sustain_s, torch):
+    """Times exactly `steps` launches between barriers (the contract's figure), then the same launch looped for
+    >= sustain_s seconds, then a per-launch spread.  Kernel durations come from HIP events on the launch stream."""
+    B = x.shape[0]
+    run = lambda: eng.eval_device(x, logits=True, probs=True, value=True)  # noqa: E731
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    s0 = eng.stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = run()
+    barrier()
+    dt_local = time.perf_counter() - t0
+    s1 = eng.stats()
+    dt = reduce_max(dt_local)
+    kern_ms = (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])
+    assert torch.isfinite(out["value"]).all() and torch.isfinite(out["probs"]).all() and torch.isfinite(out["logits"]).all()
+
+    # sustained: keep the chip busy for >= sustain_s (20-launch chunks, one sync per chunk)
+    sust = None
+    if sustain_s > 0:
+        s0 = eng.stats()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < sustain_s:
+            for _ in range(20):
+                run()
+            torch.cuda.synchronize()
+            n += 20
+        t_s = time.perf_counter() - t0
+        s1 = eng.stats()
+        sust = {"seconds": t_s, "launches": n, "leaf_evals_per_s": n * B / t_s,
+                "kernel_ms": (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])}
+    each = []
+    for _ in range(30):
+        run()
+        torch.cuda.synchronize()
+        each.append(eng.stats()["last_kernel_ms"])
+    eng.set_profiling(False)
+    return {"dt": dt, "dt_local": dt_local, "kernel_ms": kern_ms, "sustained": sust, "out": out,
+            "p10_p50_p90": [float(np.percentile(each, q)) for q in (10, 50, 90)]}
+
+
+def roofline(precision, batch, kern_ms, sust, spread):
+    f16 = precision == "f16x2"
+    peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
+    achieved = batch * FLOP_PER_LEAF / (kern_ms * 1e-3) / 1e12
+    traffic, src = measured_traffic(batch, precision)
+    r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+         "traffic": traffic, "traffic_source": src, "kernel": KERNEL[precision], "kernel_ms": kern_ms,
+         "kernel_ms_isolated_p10_p50_p90": spread,
+         "algorithmic_flop_per_launch": batch * FLOP_PER_LEAF, "algorithmic_hbm_bytes_per_launch": batch * BYTES_PER_LEAF,
+         # f16x2 executes 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC; both variants issue the dense
+         # padded work minus the zero-halo taps they skip
+         "executed_mfma_flop_per_algorithmic_flop": 3.0 if f16 else 1.0}
+    if sust:
+        r["sustained_kernel_ms"] = sust["kernel_ms"]
+        r["sustained_frac"] = batch * FLOP_PER_LEAF / (sust["kernel_ms"] * 1e-3) / 1e12 / peak
+    if f16 and batch >= 768:
+        # per 3-board task and net 41,024 MFMAs of 32x32x16 (3x3 layers: 3 products, zero-halo taps skipped; layer 0: 2)
+        r["executed_mfma_tflops"] = 2 * ((batch + 2) // 3) * 41024 * 32768 / (kern_ms * 1e-3) / 1e12
+        r["frac_of_fp32_mfma_peak"] = achieved / PEAK_FP32_MFMA_TFLOPS
+    return r
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the sustained loop per variant (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-selfplay", action="store_true", help="skip the secondary config-4 measurement")
-    ap.add_argument("--precision", choices=["f16x2", "f32"], default=os.environ.get("BK_PRECISION", "f16x2"),
-                    help="conv arithmetic: fp16 hi/lo split operands with fp32 accumulation (default) or exact fp32 MFMA")
+    ap.add_argument("--no-selfplay", action="store_true", help="skip the secondary configs[3] measurement")
+    ap.add_argument("--no-f16x2", action="store_true", help="skip the nested f16x2 block")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
+                    help="arithmetic of the HEADLINE (default f32 = the reference's width; f16x2 only for profiling that variant)")
     args = ap.parse_args()
 
     import torch
@@ -163,40 +311,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.eval_device(x, logits=True, probs=True, value=True)
-    torch.cuda.synchronize()
-    eng.set_profiling(True)
-    s0 = eng.stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = eng.eval_device(x, logits=True, probs=True, value=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    s1 = eng.stats()
-    eng.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern_ms = (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / max(1, s1["kernel_ms_count"] - s0["kernel_ms_count"])
-    assert torch.isfinite(out["value"]).all() and torch.isfinite(out["probs"]).all()
+        return float(t.item())
 
-    # per-launch spread (median and p10/p90), one launch at a time, outside the timed region
-    eng.set_profiling(True)
-    each = []
-    for _ in range(min(100, max(10, args.steps))):
-        eng.eval_device(x, logits=True, probs=True, value=True)
-        torch.cuda.synchronize()
-        each.append(eng.stats()["last_kernel_ms"])
-    eng.set_profiling(False)
-    p10, p50, p90 = (float(np.percentile(each, q)) for q in (10, 50, 90))
+    def gather(v):
+        if dist is None:
+            return [v]
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        return [float(o.item()) for o in outl]
+
+    # ---- headline: exactly --steps launches of the reference-width kernel, then the sustained loop -------------
+    head = measure(eng, x, args.steps, args.warmup, barrier, reduce_max, args.sustain, torch)
+    head_parity = parity_in_run(eng, torch)
+    per_rank = gather(args.batch * args.steps / head["dt_local"])
+    assert eng.stats()["f16_device_overflow"] == 0
+
+    # a sample of the TIMED output against the CPU oracle (the workload has no recorded reference outputs)
+    wl_check = None
+    if rank == 0:
+        from oracle.oracle import OraclePolicy, OracleValue
+        sel = np.linspace(0, args.batch - 1, 48).astype(int)
+        lg = OraclePolicy(pw)(x_host[sel])
+        va = OracleValue(vw)(x_host[sel])
+        wl_check = {"positions": len(sel),
+                    "max_abs_dlogit_vs_oracle": float(np.abs(head["out"]["logits"].cpu().numpy()[sel] - lg).max()),
+                    "max_abs_dvalue_vs_oracle": float(np.abs(head["out"]["value"].cpu().numpy()[sel] - va).max())}
+        assert wl_check["max_abs_dlogit_vs_oracle"] < 2 * TOL["logit"] and wl_check["max_abs_dvalue_vs_oracle"] < TOL["value"], wl_check
+
+    # ---- nested: the opt-in f16x2 variant, same engine, same measurements --------------------------------------------
+    other = None
+    other_name = "f16x2" if args.precision == "f32" else "f32"
+    if not args.no_f16x2:
+        eng.set_precision(other_name)
+        m = measure(eng, x, args.steps, args.warmup, barrier, reduce_max, args.sustain, torch)
+        other = {"value": world * args.batch * args.steps / m["dt"], "unit": "leaf-evals/s", "dtype": DTYPE[other_name],
+                 "ms_per_step": m["dt"] / args.steps * 1e3,
+                 "sustained": m["sustained"], "parity": parity_in_run(eng, torch),
+                 "roofline": roofline(other_name, args.batch, m["kernel_ms"], m["sustained"], m["p10_p50_p90"]),
+                 "f16_device_overflow_redos": eng.stats()["f16_device_overflow"],
+                 "max_abs_dlogit_vs_headline_on_workload": float((m["out"]["logits"] - head["out"]["logits"]).abs().max().item())}
+        eng.set_precision(args.precision)
 
     # PCIe-inclusive rates through the host-buffer ABI (reported beside, never as `value`):
     # (a) synchronous bk_eval with f32 planes, as the reference's host tensors would arrive;
     # (b) what the ABI is built for: uint8 planes, three tickets in flight (the engine runs H2D, kernels
-    #     and D2H on three streams chained by events).
+    #     and D2H on three streams chained by events); (c) 192-byte position records, planes encoded on the GPU.
     e2e = e2e_u8 = e2e_pos = None
     if rank == 0:
         eng.eval(x_host, logits=False, probs=True, value=True)
@@ -205,91 +370,71 @@ def main():
             eng.eval(x_host, logits=False, probs=True, value=True)
         e2e = 3 * args.batch / (time.perf_counter() - t1)
         x_u8 = x_host.astype(np.uint8)
-        eng.wait(eng.submit(x_u8, logits=False, probs=True, value=True))
-        t1 = time.perf_counter()
-        pend, n_e2e = [], 32
-        for _ in range(n_e2e):                       # three tickets in flight: H2D / kernel / D2H streams overlap
-            pend.append(eng.submit(x_u8, logits=False, probs=True, value=True))
-            if len(pend) == 3:
-                eng.wait(pend.pop(0))
-        while pend:
-            eng.wait(pend.pop(0))
-        e2e_u8 = n_e2e * args.batch / (time.perf_counter() - t1)
-        # (c) 192-byte position records in, planes encoded on the GPU (bk_submit_positions)
         ref = eng.eval(x_u8, logits=False, probs=True, value=True)
         got = eng.wait(eng.submit_positions(x_recs, logits=False, probs=True, value=True))
         assert np.array_equal(ref["probs"], got["probs"]) and np.array_equal(ref["value"], got["value"])
-        t1 = time.perf_counter()
-        for _ in range(n_e2e):
-            pend.append(eng.submit_positions(x_recs, logits=False, probs=True, value=True))
-            if len(pend) == 3:
-                eng.wait(pend.pop(0))
-        while pend:
-            eng.wait(pend.pop(0))
-        e2e_pos = n_e2e * args.batch / (time.perf_counter() - t1)
 
-    # Secondary measurement (outside the timed region above): BASELINE config 4 -- 512 self-play games,
+        def pipelined(submit, n_e2e=16):
+            pend, t1 = [], time.perf_counter()
+            for _ in range(n_e2e):                   # three tickets in flight: H2D / kernel / D2H streams overlap
+                pend.append(submit())
+                if len(pend) == 3:
+                    eng.wait(pend.pop(0))
+            while pend:
+                eng.wait(pend.pop(0))
+            return n_e2e * args.batch / (time.perf_counter() - t1)
+        e2e_u8 = pipelined(lambda: eng.submit(x_u8, logits=False, probs=True, value=True))
+        e2e_pos = pipelined(lambda: eng.submit_positions(x_recs, logits=False, probs=True, value=True))
+
+    # Secondary measurement (outside the timed region above): BASELINE configs[3] -- 512 self-play games,
     # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
     sp = None
     if not args.no_selfplay:
         from bokego_amd import selfplay
-        ev = selfplay.EngineEvaluator(eng)
-        barrier()
         threads = max(1, min(16, len(os.sched_getaffinity(0)) // world))  # host cores are shared by the ranks
-        local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
-                                          reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-        secs = local["seconds"]
-        if dist is not None:
-            t = torch.tensor([secs], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            secs = float(t.item())
-        sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus", "games": total["games"],
-              "games_per_min": total["games"] / secs * 60, "seconds": secs, "plies": total["plies"],
-              "value_evals_per_s": total["value_evals"] / secs, "black_wins": total["black_wins"],
-              "stats_allreduce_ms": local["allreduce_s"] * 1e3, "host_threads_per_rank": threads, "collective": "1 all-reduce of 89 doubles per generation"}
+        sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus",
+              "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads}
+        for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
+            eng.set_precision(prec)
+            ev = selfplay.EngineEvaluator(eng)
+            barrier()
+            local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
+                                              reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+            secs = reduce_max(local["seconds"])
+            sp[prec] = {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
+                        "plies": total["plies"], "value_evals_per_s": total["value_evals"] / secs,
+                        "black_wins": total["black_wins"], "stats_allreduce_ms": local["allreduce_s"] * 1e3,
+                        "first_move_hist_sum": int(sum(total["first_move_hist"]))}
+        eng.set_precision(args.precision)
+        sp["games_per_min"] = sp[args.precision]["games_per_min"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pw, vw, x_host)
         if sp is not None:
-            sp["cpu_baseline"] = selfplay_cpu_baseline(pw, vw, sp["plies"] / max(1.0, sp["games"]))
+            sp["cpu_baseline"] = selfplay_cpu_baseline(cpu["cores"])
 
     if rank == 0:
-        value = world * args.batch * args.steps / dt
-        achieved = args.batch * FLOP_PER_LEAF / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(args.batch)
-        f16 = args.precision == "f16x2"
-        # f16x2 executes 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC; the roofline is
-        # priced strictly: algorithmic FLOP over the dense MFMA peak of the dtype the matrix unit runs.
-        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
-        assert eng.stats()["f16_device_overflow"] == 0
+        value = world * args.batch * args.steps / head["dt"]
         line = {
             "metric": "leaf-evals/sec (policy+value, batched 9x9 positions)",
             "value": value, "unit": "leaf-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16x2 (fp16 hi/lo split operands = 22-bit significands, fp32 accumulate)" if f16 else "f32",
+            "ms_per_step": head["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE[args.precision],
             "data": "synthetic (seeded random-playout positions, SURVEY 8d recipe)",
             "config": {"workload": f"configs[1]: batch={args.batch} 9x9 positions, PolicyNet logits+softmax and "
                                    "ValueNet, device-resident inputs/outputs",
                        "batch_per_gpu": args.batch, "weights": "policy_19 + value_synth (tests/golden)",
-                       "precision": args.precision, "parity": "max |dlogit| 5.3e-5 vs reference goldens (tol 1e-4)",
+                       "precision": args.precision, "parity": head_parity, "parity_workload_sample": wl_check,
                        "sharding": f"positions x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "bk_leaf_eval_f16_kernel<3>" if f16 else "bk_leaf_eval_kernel<3>",
-                         "kernel_ms": kern_ms,
-                         "kernel_ms_isolated_p10_p50_p90": [p10, p50, p90],
-                         "algorithmic_flop_per_launch": args.batch * FLOP_PER_LEAF,
-                         "algorithmic_hbm_bytes_per_launch": args.batch * BYTES_PER_LEAF,
-                         "executed_mfma_flop_per_algorithmic_flop": 3.0 if f16 else 1.0,
-                         # what the matrix unit really issued: per 3-board task and net 41,024 MFMAs of
-                         # 32x32x16 (3x3 layers: 3 products, zero-halo taps skipped; layer 0: 2 products)
-                         "executed_mfma_tflops": (2 * ((args.batch + 2) // 3) * 41024 * 32768 / (kern_ms * 1e-3) / 1e12)
-                         if f16 and args.batch >= 768 else None,
-                         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
+            "sustained": head["sustained"],
+            "roofline": roofline(args.precision, args.batch, head["kernel_ms"], head["sustained"], head["p10_p50_p90"]),
+            other_name: other,
             "cpu_baseline": cpu,
             "selfplay": sp,
+            "collective_ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "collective_backend": (backend if dist is not None else None),
+            "per_rank_leaf_evals_per_s": per_rank,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,
             "host_positions_e2e_pipelined_leaf_evals_per_s": e2e_pos,

@@ -67,23 +67,52 @@ class NativeComm:
             raise RuntimeError("bk_comm_unique_id: " + lib.bk_comm_last_error().decode())
         return bytes(buf)
 
+    @staticmethod
+    def _job_tag(job):
+        """16 bytes that every rank of ONE launch derives identically and another launch does not: the caller's
+        `job`, else BK_COMM_JOB, else what torch.distributed.run exports per launch (run id + master port)."""
+        import hashlib
+        if job is None:
+            job = os.environ.get("BK_COMM_JOB") or "|".join(os.environ.get(k, "") for k in
+                                                             ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+        return hashlib.sha256(str(job).encode()).digest()[:16]
+
     @classmethod
-    def create(cls, rank, world, device_id, id_path, timeout=120.0):
-        """Rendezvous through a file every rank can see: rank 0 writes the id, the others wait for it."""
+    def create(cls, rank, world, device_id, id_path, timeout=120.0, job=None):
+        """Rendezvous through a file every rank can see: rank 0 writes [job tag | id], the others wait for a file
+        carrying THEIR job tag (a file left behind by another job, or by a crashed run with another tag, is
+        ignored); rank 0 removes a stale file before writing and its own file once every rank has joined."""
+        tag = cls._job_tag(job)
         if rank == 0:
+            try:
+                os.unlink(id_path)
+            except FileNotFoundError:
+                pass
             uid = cls.unique_id()
             tmp = f"{id_path}.{os.getpid()}"
             with open(tmp, "wb") as f:
-                f.write(uid)
+                f.write(tag + uid)
             os.replace(tmp, id_path)
         else:
             t0 = time.time()
-            while not (os.path.exists(id_path) and os.path.getsize(id_path) == ID_BYTES):
+            while True:
+                try:
+                    blob = open(id_path, "rb").read()
+                except FileNotFoundError:
+                    blob = b""
+                if len(blob) == 16 + ID_BYTES and blob[:16] == tag:
+                    break
                 if time.time() - t0 > timeout:
-                    raise RuntimeError(f"no communicator id at {id_path} after {timeout}s")
+                    raise RuntimeError(f"no communicator id for this job at {id_path} after {timeout}s")
                 time.sleep(0.01)
-            uid = open(id_path, "rb").read()
-        return cls(rank, world, device_id, uid)
+            uid = blob[16:]
+        comm = cls(rank, world, device_id, uid)   # collective: returns once all ranks have joined
+        if rank == 0:
+            try:
+                os.unlink(id_path)
+            except FileNotFoundError:
+                pass
+        return comm
 
     def allreduce_sum(self, vec):
         a = np.ascontiguousarray(vec, np.float64).copy()

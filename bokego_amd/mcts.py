@@ -63,6 +63,26 @@ class Go_MCTS(go.Game):
     def copy(self):
         return self._from_pos(go.Pos.from_buffer_copy(self._pos), self.komi)
 
+    # pickling (reference mcts.py:279-292 ships board/ko/turn/last_move + the liberty cache; the 192-byte record
+    # holds exactly that).  Statistics and memoised outputs travel too; the tree link is restored by
+    # MCTS.__setstate__, the Categorical and the planes are rebuilt on demand.
+    def __getstate__(self):
+        return {"pos": bytes(self._pos), "komi": self.komi, "N": self.N, "V": self.V, "Q": self.Q, "kids": self._kids,
+                "prior": self._prior, "value": self._value}
+
+    def __setstate__(self, st):
+        self._pos = go.Pos.from_buffer_copy(st["pos"])
+        self.moves, self.komi, self.sgf = None, st["komi"], None
+        self._init_node()
+        self.N, self.V, self.Q, self._kids = st["N"], st["V"], st["Q"], st["kids"]
+        self._prior, self._value = st["prior"], st["value"]
+
+    def _clone_with_stats(self):
+        c = self.copy()
+        c.N, c.V, c.Q, c._value, c._fts = self.N, self.V, self.Q, self._value, self._fts
+        c._prior = list(self._prior) if self._prior is not None else None
+        return c
+
     def is_game_over(self):
         """Terminal after MAX_TURNS or when the last move was a pass (mcts.py:362-364)."""
         return self._pos.turn > MAX_TURNS or self._pos.last_move == go.PASS
@@ -352,14 +372,21 @@ class MCTS:
         self._table = keep
 
     # ---- evaluation plumbing --------------------------------------------------------------------------------
+    def _ev(self):
+        if self.evaluator is None:   # an unpickled tree: the caller puts the nets back by hand (mcts.py:105-107)
+            if self.policy_net is None or (self.no_sim and self.value_net is None):
+                raise TypeError("this tree was unpickled without its nets: set tree.policy_net / tree.value_net first")
+            self.evaluator = Evaluator(self.policy_net, self.value_net, self.device)
+        return self.evaluator
+
     def _eval_now(self, policy_nodes, value_nodes):
-        self.evaluator.run([EvalRequest(policy_nodes, value_nodes)])
+        self._ev().run([EvalRequest(policy_nodes, value_nodes)])
 
     def _drive(self, gen):
         try:
             req = next(gen)
             while True:
-                self.evaluator.run([req])
+                self._ev().run([req])
                 req = gen.send(None)
         except StopIteration as e:
             return e.value
@@ -504,3 +531,41 @@ class MCTS:
         for k in ("policy_net", "value_net", "evaluator"):
             d[k] = None
         return d
+
+    def __setstate__(self, state):
+        """mcts.py:97-108: restore the dicts, give every node its tree back, leave the nets to the caller
+        (`tree.policy_net = ...; tree.value_net = ...`; the evaluator is rebuilt on first use)."""
+        self.__dict__.update(state)
+        self._relink()
+        self.policy_net = self.value_net = self.evaluator = None
+
+    def _relink(self):
+        for n in self._table.values():
+            n.tree = self
+            for c in n._kids or ():
+                c.tree = self
+        for view in (self.N, self.V, self.Q, self.children):
+            view._tree = self
+
+    def __deepcopy__(self, memo):
+        """mcts.py:81-90: an independent copy of the search state (root, N, V, Q, children) that shares the
+        networks -- and here the evaluator -- with the original."""
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        clones = {}
+
+        def clone(n):
+            c = clones.get(id(n))
+            if c is None:
+                clones[id(n)] = c = n._clone_with_stats()
+            return c
+
+        new._table = {k: clone(n) for k, n in self._table.items()}
+        for n in list(self._table.values()):
+            if n._kids is not None:
+                clone(n)._kids = [clone(k) for k in n._kids]
+        new.root = clone(self.root) if self.root is not None else None
+        new.N, new.V, new.Q = _StatView(new, "N", 0), _StatView(new, "V", 0.0), _StatView(new, "Q", 0)
+        new.children = _ChildrenView(new)
+        new._relink()
+        return new

@@ -130,19 +130,31 @@ int main(int argc, char **argv) {
         const char *idf = getenv("BK_COMM_ID_FILE");
         uint8_t id[BK_COMM_ID_BYTES];
         if (!idf) { fprintf(stderr, "BK_WORLD > 1 needs BK_COMM_ID_FILE\n"); return 1; }
+        /* the file is [16-byte job tag | id]: a file left by another launch (other BK_COMM_JOB) is not ours */
+        char tag[16] = {0}, got[16];
+        const char *job = getenv("BK_COMM_JOB");
+        if (job) strncpy(tag, job, sizeof tag);
         if (rank == 0) {
             if (bk_comm_unique_id(id)) { fprintf(stderr, "%s\n", bk_comm_last_error()); return 1; }
             char tmp[4096];
             snprintf(tmp, sizeof tmp, "%s.tmp", idf);
-            FILE *f = fopen(tmp, "wb"); fwrite(id, 1, sizeof id, f); fclose(f); rename(tmp, idf);
+            remove(idf);
+            FILE *f = fopen(tmp, "wb"); fwrite(tag, 1, sizeof tag, f); fwrite(id, 1, sizeof id, f); fclose(f); rename(tmp, idf);
         } else {
-            FILE *f;
-            while (!(f = fopen(idf, "rb"))) usleep(10000);
-            if (fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "short id file\n"); return 1; }
-            fclose(f);
+            for (;;) {
+                FILE *f = fopen(idf, "rb");
+                if (f) {
+                    const int ok = fread(got, 1, sizeof got, f) == sizeof got && fread(id, 1, sizeof id, f) == sizeof id &&
+                                   !memcmp(got, tag, sizeof tag);
+                    fclose(f);
+                    if (ok) break;
+                }
+                usleep(10000);
+            }
         }
         bk_comm *c = NULL;
         if (bk_comm_init(rank, world, id, device, &c)) { fprintf(stderr, "bk_comm_init: %s\n", bk_comm_last_error()); return 1; }
+        if (rank == 0) remove(idf);   /* every rank has joined: the next run must not find this id */
         const double t1 = now();
         if (bk_comm_allreduce_sum_f64(c, st, 8 + 81)) { fprintf(stderr, "allreduce: %s\n", bk_comm_last_error()); return 1; }
         reduce_ms = (now() - t1) * 1e3;

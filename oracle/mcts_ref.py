@@ -116,3 +116,54 @@ class RefMCTS:
                 best, best_n = (m, ck), s
         self.set_root(self.state[best[1]])
         return best[0]
+
+
+def play_game(policy_fn, value_fn, rollouts=400, seed=0, sample_plies=2, max_plies=200):
+    """One full self-play game of the sequential tree (bench.py's CPU leg of configs[3]): `rollouts` per move, the
+    first `sample_plies` moves drawn in proportion to the root-child visits (so that games with different seeds
+    differ), then the most-visited child, until a pass or turn > 80.  Returns (moves, seconds, network calls)."""
+    import time
+    rng = np.random.default_rng(seed)
+    m = RefMCTS(policy_fn, value_fn)
+    moves, t0 = [], time.perf_counter()
+    while len(moves) < max_plies and not m._terminal(m.state[m.root]):
+        m.rollout(rollouts)
+        if not m.children[m.root]:
+            break
+        if len(moves) < sample_plies:
+            vis = m.child_visits()
+            mv = list(vis)
+            p = np.array([vis[k] for k in mv], np.float64)
+            pick = mv[int(rng.choice(len(mv), p=p / p.sum()))]
+            m.set_root(m.state[dict(m.children[m.root])[pick]])
+            moves.append(pick)
+        else:
+            moves.append(m.choose())
+    return moves, time.perf_counter() - t0, m.n_policy_calls + m.n_value_calls
+
+
+def _worker_main():
+    """python -m oracle.mcts_ref --seed S --rollouts R: one game on ONE core with the torch restatement of the
+    reference's nets (oracle/torch_ref.py), batch-1 calls as the reference makes them; prints one JSON line."""
+    import argparse
+    import json
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rollouts", type=int, default=400)
+    ap.add_argument("--max-plies", type=int, default=200)
+    a = ap.parse_args()
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch
+    torch.set_num_threads(1)
+    from bokego_amd.bkw import load_bkw
+    from oracle.torch_ref import TorchPolicy, TorchValue
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    P, V = TorchPolicy(load_bkw(os.path.join(g, "policy_19.bkw"))), TorchValue(load_bkw(os.path.join(g, "value_synth.bkw")))
+    moves, secs, calls = play_game(lambda f: P(torch.from_numpy(f)).numpy(), lambda f: V(torch.from_numpy(f)).numpy(),
+                                   a.rollouts, a.seed, max_plies=a.max_plies)
+    print(json.dumps({"plies": len(moves), "seconds": secs, "net_calls": calls, "seed": a.seed}), flush=True)
+
+
+if __name__ == "__main__":
+    _worker_main()

@@ -132,3 +132,40 @@ def test_noise_and_branching(nets):
     assert abs(p.sum().item() - 1) < 1e-4 and p[40] < 0.82     # noise moved mass away from the 0.8186 top move
     tree.rollout(40)
     assert tree.N[tree.root] == 40
+
+
+def test_pickle_and_deepcopy_keep_the_search_state(nets):
+    """MCTS.__getstate__/__setstate__/__deepcopy__ (reference mcts.py:81-108): a pickled tree comes back without
+    its nets and with every node linked to it; once the nets are put back it continues EXACTLY like the original;
+    a deepcopy shares the nets and diverges from the original only by what is searched afterwards."""
+    import copy
+    import pickle
+    P, V = _TorchWrap(nets[0]), _TorchWrap(nets[1], True)
+    torch.manual_seed(0)
+    a = MCTS(Go_MCTS(), P, V, no_sim=True, expand_thresh=10)
+    a.rollout(150)
+    a.choose()
+    a.rollout(60)
+    snap = {c.mv: (a.N[c], a.V[c]) for c in a.children[a.root]}
+
+    b = pickle.loads(pickle.dumps(a))
+    assert b.policy_net is None and b.value_net is None
+    assert b.root.key() == a.root.key() and b.root.tree is b
+    assert all(n.tree is b for n in b.N) and len(b.N) == len(a.N)
+    assert {c.mv: (b.N[c], b.V[c]) for c in b.children[b.root]} == snap
+    with pytest.raises(TypeError):
+        b._eval_now([Go_MCTS()], [])                   # nets have to be put back first, as in the reference
+    b.policy_net, b.value_net = P, V
+
+    c = copy.deepcopy(a)
+    assert c.policy_net is P and c.root is not a.root and c.root.key() == a.root.key()
+    assert {k.mv: (c.N[k], c.V[k]) for k in c.children[c.root]} == snap
+    c.rollout(40)                                      # searching the copy leaves the original alone
+    assert {k.mv: (a.N[k], a.V[k]) for k in a.children[a.root]} == snap
+
+    a.rollout(40)
+    b.rollout(40)
+    after = {k.mv: (a.N[k], a.V[k]) for k in a.children[a.root]}
+    assert {k.mv: (b.N[k], b.V[k]) for k in b.children[b.root]} == after
+    assert {k.mv: (c.N[k], c.V[k]) for k in c.children[c.root]} == after
+    assert a.choose().last_move == b.choose().last_move == c.choose().last_move

@@ -76,3 +76,24 @@ def test_hard_positions(nets):
     f = h["features"].astype(np.float32)
     assert np.abs(nets[0](f) - h["logits"]).max() < TOL_LOGIT
     assert np.abs(nets[1](f) - h["values"]).max() < TOL_VALUE
+
+
+def test_torch_restatement_matches_reference(gold):
+    """oracle/torch_ref.py (the reference's ops re-assembled on torch CPU; bench.py's reference-CPU baseline) against
+    the reference's own outputs: B=1 and batched, policy logits / softmax / value."""
+    import torch
+    from oracle.torch_ref import TorchPolicy, TorchValue, leaf_eval
+    f, n = gold
+    P = TorchPolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")))
+    V = TorchValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw")))
+    x = torch.from_numpy(f)
+    lg, pr, va = leaf_eval(P, V, x)
+    assert np.abs(lg.numpy() - n["logits_b64"]).max() < TOL_LOGIT and np.abs(lg.numpy() - n["logits_b1"]).max() < TOL_LOGIT
+    assert np.abs(pr.numpy() - n["probs_b1"]).max() < TOL_PROB
+    assert np.abs(va.numpy() - n["values_b1"]).max() < TOL_VALUE
+    for i in (0, 17, 300, 535):
+        l1, _, v1 = leaf_eval(P, V, x[i:i + 1])
+        assert np.abs(l1.numpy() - n["logits_b1"][i]).max() < TOL_LOGIT and abs(float(v1) - n["values_b1"][i]) < TOL_VALUE
+    h = np.load(os.path.join(GOLDEN, "hard_positions.npz"))
+    lg, _, va = leaf_eval(P, V, torch.from_numpy(h["features"].astype(np.float32)))
+    assert np.abs(lg.numpy() - h["logits"]).max() < TOL_LOGIT and np.abs(va.numpy() - h["values"]).max() < TOL_VALUE

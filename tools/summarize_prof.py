@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_bench.sh output directory into profiles/<tag>_*.{csv,md} (tracked)."""
+"""Condense a tools/profile_bench.sh output directory into profiles/<tag>_*.{csv,md,json} (tracked).
+
+    profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default bench (both kernels)
+    profiles/<tag>_bench.json            the un-profiled bench line of the same box
+    profiles/<tag>_pmc_<precision>.json  PMC means per dispatch of that precision's kernel (+ HBM traffic)
+    profiles/<tag>_summary.md            the table the DESIGN / VERDICT numbers are read from
+"""
 import collections
 import csv
 import glob
@@ -8,66 +14,78 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
+KERNEL_OF = {"f32": "bk_leaf_eval_kernel<3, false>", "f16x2": "bk_leaf_eval_f16_kernel<3>"}
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
-
 rows = list(csv.DictReader(open(stats)))
-kern = [r for r in rows if "bk_leaf_eval" in r["Name"]][0]
-pmc = collections.OrderedDict()
-meta = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "bk_leaf_eval" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
-    for k, v in agg.items():
-        pmc[k] = (sum(v) / len(v), len(v))
-
-avg_ms = float(kern["AverageNs"]) / 1e6
 B = bench["config"]["batch_per_gpu"]
+
+
+def bench_block(prec):
+    return bench if bench["config"]["precision"] == prec else bench.get(prec)
+
+
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     o.write(f"# rocprofv3 summary {tag} (MI355X, `python3 bench.py`, batch {B})\n\n")
-    o.write("## --kernel-trace --stats\n\n| kernel | calls | avg ms | min ms | max ms | % |\n|---|---|---|---|---|---|\n")
-    for r in rows[:4]:
-        o.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {float(r['MinNs'])/1e6:.4f} | "
+    o.write("## --kernel-trace --stats (one run: fp32 headline + nested f16x2 block)\n\n| kernel | calls | avg ms | min ms | max ms | % |\n|---|---|---|---|---|---|\n")
+    for r in rows[:6]:
+        o.write(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {float(r['MinNs'])/1e6:.4f} | "
                 f"{float(r['MaxNs'])/1e6:.4f} | {r['Percentage']} |\n")
-    o.write(f"\nbench.py HIP-event kernel time (un-profiled run): {bench['roofline']['kernel_ms']:.4f} ms; "
-            f"rocprofv3 average: {avg_ms:.4f} ms.\n")
-    o.write(f"\nDispatch: {meta}\n\n## --pmc passes (mean per dispatch of the leaf-eval kernel)\n\n| counter | mean | n |\n|---|---|---|\n")
-    for k, (m, n) in pmc.items():
-        o.write(f"| {k} | {m:.6g} | {n} |\n")
-    g = pmc.get("GRBM_GUI_ACTIVE", (0, 0))[0]
-    if g:
-        o.write(f"\nEffective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time = {g/8/(avg_ms*1e-3)/1e9:.3f} GHz\n")
-    mf = pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0]
-    if mf and g:
-        o.write(f"MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE/8) = {mf/1024/(g/8)*100:.1f} %\n")
-    fs, ws = pmc.get("FETCH_SIZE", (0, 0))[0], pmc.get("WRITE_SIZE", (0, 0))[0]
-    if fs:
-        traffic = (2 * fs + ws) * 1024
-        o.write(f"Fabric-side traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = {traffic/1e6:.1f} MB "
-                f"(gfx950 FETCH_SIZE correction x2, MI355X_MICROARCH.md HBM section); algorithmic "
-                f"{bench['roofline']['algorithmic_hbm_bytes_per_launch']/1e6:.1f} MB + 7.9 MB weights. "
-                f"= {traffic/(avg_ms*1e-3)/1e9:.1f} GB/s vs 8000 GB/s peak.\n")
-    h, m = pmc.get("TCC_HIT_sum", (0, 0))[0], pmc.get("TCC_MISS_sum", (0, 0))[0]
-    if h:
-        o.write(f"L2 hit rate = {h/(h+m)*100:.2f} %\n")
-    c, a = pmc.get("SQ_LDS_BANK_CONFLICT", (0, 0))[0], pmc.get("SQ_LDS_IDX_ACTIVE", (0, 0))[0]
-    if a:
-        o.write(f"LDS: bank-conflict cycles / active cycles = {c/a*100:.1f} %; LDS active = {a/256/(g/8)*100:.1f} % of CU time\n")
-fs, ws = pmc.get("FETCH_SIZE", (0, 0))[0], pmc.get("WRITE_SIZE", (0, 0))[0]
-json.dump({"tag": tag, "precision": bench["config"].get("precision"), "kernel": kern["Name"], "rocprof_avg_kernel_ms": avg_ms, "batch": B,
-           "counters": {k: v[0] for k, v in pmc.items()},
-           "hbm_traffic_bytes_per_launch": (2 * fs + ws) * 1024 if fs else None,
-           "traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction"},
-          open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+    for prec, kname in KERNEL_OF.items():
+        kern = [r for r in rows if kname in r["Name"]]
+        blk = bench_block(prec)
+        if not kern or not blk:
+            continue
+        kern = kern[0]
+        avg_ms = float(kern["AverageNs"]) / 1e6
+        rf = blk["roofline"]
+        o.write(f"\n## {prec}: `{kname}`\n\nbench.py HIP-event kernel time (un-profiled run): {rf['kernel_ms']:.4f} ms "
+                f"(sustained loop {rf.get('sustained_kernel_ms', float('nan')):.4f} ms); rocprofv3 average: {avg_ms:.4f} ms over {kern['Calls']} calls.\n"
+                f"roofline.frac = {rf['frac']:.4f} of {rf['peak']} TFLOP/s (sustained {rf.get('sustained_frac', float('nan')):.4f}); "
+                f"from the rocprofv3 average: {B * 266838272 / (avg_ms * 1e-3) / 1e12 / rf['peak']:.4f}.\n")
+        pmc, meta = collections.OrderedDict(), {}
+        for f in sorted(glob.glob(os.path.join(src, f"pmc_{prec}_*", "*", "*_counter_collection.csv"))):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if kname in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            for k, v in agg.items():
+                pmc[k] = (sum(v) / len(v), len(v))
+        if not pmc:
+            continue
+        o.write(f"\nDispatch: {meta}\n\n--pmc passes (mean per dispatch):\n\n| counter | mean | n |\n|---|---|---|\n")
+        for k, (m, n) in pmc.items():
+            o.write(f"| {k} | {m:.6g} | {n} |\n")
+        g = pmc.get("GRBM_GUI_ACTIVE", (0, 0))[0]
+        if g:
+            o.write(f"\nEffective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time = {g/8/(avg_ms*1e-3)/1e9:.3f} GHz\n")
+        mf = pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0]
+        if mf and g:
+            o.write(f"MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE/8) = {mf/1024/(g/8)*100:.1f} %\n")
+        fs, ws = pmc.get("FETCH_SIZE", (0, 0))[0], pmc.get("WRITE_SIZE", (0, 0))[0]
+        traffic = (2 * fs + ws) * 1024 if fs else None
+        if fs:
+            o.write(f"Fabric-side traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = {traffic/1e6:.1f} MB "
+                    f"(gfx950 FETCH_SIZE correction x2, MI355X_MICROARCH.md HBM section); algorithmic "
+                    f"{rf['algorithmic_hbm_bytes_per_launch']/1e6:.1f} MB + 7.9 MB weights. "
+                    f"= {traffic/(avg_ms*1e-3)/1e9:.1f} GB/s vs 8000 GB/s peak.\n")
+        h, m = pmc.get("TCC_HIT_sum", (0, 0))[0], pmc.get("TCC_MISS_sum", (0, 0))[0]
+        if h:
+            o.write(f"L2 hit rate = {h/(h+m)*100:.2f} %\n")
+        c, a = pmc.get("SQ_LDS_BANK_CONFLICT", (0, 0))[0], pmc.get("SQ_LDS_IDX_ACTIVE", (0, 0))[0]
+        if a and g:
+            o.write(f"LDS: bank-conflict cycles / active cycles = {c/a*100:.1f} %; LDS active = {a/256/(g/8)*100:.1f} % of CU time\n")
+        json.dump({"tag": tag, "precision": prec, "kernel": kern["Name"], "rocprof_avg_kernel_ms": avg_ms, "batch": B,
+                   "counters": {k: v[0] for k, v in pmc.items()}, "hbm_traffic_bytes_per_launch": traffic,
+                   "traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction"},
+                  open(os.path.join(dst, f"{tag}_pmc_{prec}.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
