@@ -286,6 +286,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     }
     a.overflow = d_flag;
     a.overflow_tag = tag;
+    a.gate_count = 1;
     gated_redo = gated_redo && precision == BK_PRECISION_F16X2 && d_flag;
     auto launch = [&](const bk_eval_args& args, int nb) {
         if (precision != BK_PRECISION_F16X2) return bk_launch_leaf_eval(args, nb, stream);
@@ -323,6 +324,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         bk_eval_args h = a;
         h.B_policy = 3 * head_p;
         h.B_value = 3 * head_v;
+        h.gate_count = 0;  // the tail launch counts for the call
         HIP_TRY(e, launch(h, 3));
         bk_eval_args t = a;
         t.off_p = 3 * head_p;

@@ -57,6 +57,7 @@ struct bk_eval_args {
     // once unless gate[0] == gate_tag (the f16x2 kernel of the same call raised the flag); gate[1] counts redone calls
     unsigned int* gate;
     unsigned int gate_tag;
+    int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
+        if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem;

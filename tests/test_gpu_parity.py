@@ -370,3 +370,43 @@ def test_split_launch_is_bit_identical(precision, monkeypatch):
         for k in ("logits", "probs", "value"):
             if k in b:
                 assert np.array_equal(a[k], b[k]), k
+
+
+def _sweep_weight_sets():
+    """set A = the goldens' nets; set B = the two trained trunks swapped + another seeded value head
+    (tools/gen_sweep_reference.py; value_synth.bkw carries every policy_17 tensor)."""
+    p19, vs = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    head_b = np.load(os.path.join(GOLDEN, "value_head_b.npz"))
+    val_b = dict(p19)
+    val_b.update({k: head_b[k] for k in head_b.files})
+    return {"A": (p19, vs), "B": ({k: v for k, v in vs.items() if k.startswith("conv.")}, val_b)}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("wset", ["A", "B"])
+def test_sweep_worst_cases_vs_reference(precision, wset):
+    """The worst positions of the 49,152-position x 2-weight-set sweep AGAINST THE REFERENCE (not kernel vs kernel):
+    tools/gen_sweep_reference.py ran the reference (fp32 and float64) over the whole sweep, tools/sweep_vs_reference.py
+    both kernels on the GPU, and the positions with the largest |dlogit| / |dvalue| / |dprob| of either kernel became
+    this fixture.  tests/golden/sweep_summary.json records the sweep-wide worst case: every figure is < 1e-4."""
+    import json
+    from bokego_amd.engine import LeafEngine
+    w = np.load(os.path.join(GOLDEN, "sweep_worst.npz"))
+    pw, vw = _sweep_weight_sets()[wset]
+    eng = LeafEngine(pw, vw, max_batch=256, precision=precision)
+    out = eng.eval(w[f"features_{wset}"], logits=True, probs=True, value=True)
+    st = eng.stats()
+    eng.close()
+    lg, va = w[f"logits_{wset}"], w[f"values_{wset}"]
+    dl = np.abs(out["logits"] - lg).max()
+    assert dl < TOL_LOGIT and np.abs(out["value"] - va).max() < TOL_VALUE
+    e = np.exp(lg.astype(np.float64) - lg.max(1, keepdims=True))
+    assert np.abs(out["probs"] - e / e.sum(1, keepdims=True)).max() < TOL_PROB
+    assert st["f16_overflow_fallbacks"] == 0
+    # what the sweep recorded for this kernel on the WHOLE sweep is reproduced here on its worst positions
+    rec = json.load(open(os.path.join(GOLDEN, "sweep_summary.json")))[wset][precision]
+    assert rec["dlogit_vs_reference"]["positions_over_1e-4"] == 0 and rec["dvalue_vs_reference"]["positions_over_1e-4"] == 0
+    assert abs(dl - rec["dlogit_vs_reference"]["max"]) < 2e-5
+    # no further from the float64 ground truth than 2x the reference's own fp32 rounding
+    ref_noise = np.abs(lg - w[f"logits_f64_{wset}"]).max()
+    assert np.abs(out["logits"] - w[f"logits_f64_{wset}"]).max() < 2 * ref_noise + 2e-5

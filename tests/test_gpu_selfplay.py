@@ -1,0 +1,218 @@
+"""-m gpu: the callers of the path on the HIP nets -- BASELINE configs[3] at its stated size (512 games x 400
+rollouts/move), the reference's policy playouts (bin/selfplay.py:18-57) seed-matched against oracle-backed nets,
+and the on-disk formats end to end (.pt checkpoint -> launcher -> engine; self-play records re-read)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from bokego_amd import go, nnet, selfplay
+from bokego_amd.bkw import load_bkw, tensors_to_state_dict
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sds():
+    return load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+
+
+@pytest.fixture(scope="module")
+def engine(sds):
+    from bokego_amd.engine import LeafEngine
+    e = LeafEngine(sds[0], sds[1], max_batch=8192)      # default precision: fp32, the reference's width
+    assert e.precision == "f32"
+    yield e
+    e.close()
+
+
+# ---- configs[3] at full size ------------------------------------------------------------------------------------------
+CFG4 = dict(n_games=512, rollouts=400, cap=8192)
+
+
+@pytest.fixture(scope="module")
+def generation(engine):
+    """ONE rank playing all 512 games (what bench.py's selfplay block times)."""
+    local, total = selfplay.self_play(selfplay.EngineEvaluator(engine), record_visits=1, **CFG4)
+    return local, total
+
+
+def test_config4_full_size_is_independent_of_sharding(engine, generation):
+    """512 games x 400 rollouts/move: the same games played as the two shards of a world-size-2 job, one after the
+    other on this GPU, give the same per-game move lists, and their statistics add up to the one-rank generation's
+    (SURVEY 8d config 4's invariant: `gid % world`, seeds `seed_base + gid`, selfplay.py:177-199)."""
+    local, total = generation
+    assert total["games"] == 512 and len(local["games"]) == 512
+    assert 512 * 40 < total["plies"] <= 512 * 81 and total["black_wins"] + total["white_wins"] == 512
+    assert sum(total["first_move_hist"]) == 512
+    assert len({tuple(g["moves"]) for g in local["games"].values()}) > 400        # the games really differ
+    shards, stats = {}, np.zeros(selfplay.STATS_LEN)
+    for rank in range(2):
+        loc, _ = selfplay.self_play(selfplay.EngineEvaluator(engine), rank=rank, world=2, **CFG4)
+        assert sorted(loc["games"]) == selfplay.shard_game_ids(512, rank, 2)
+        shards.update(loc["games"])
+        stats += loc["local_stats"]
+    assert shards == local["games"]                                                # (i) move lists and scores, every game
+    assert np.array_equal(stats, local["local_stats"])                             # (ii) what the all-reduce would sum
+    named = {k: float(stats[i]) for i, k in enumerate(selfplay.STATS_FIELDS)}
+    assert all(named[k] == total[k] for k in selfplay.STATS_FIELDS)
+
+
+def test_config4_games_start_like_the_cpu_oracle_run(generation, sds):
+    """(iii) anchored to the oracle, not to the HIP path itself: the native pool driven by the CPU oracle nets
+    (CallableEvaluator) plays the first plies of sampled games of the SAME generation (same seeds, 400 rollouts,
+    Dirichlet noise and visit sampling included); moves and root visit counts must equal the GPU run's."""
+    from oracle.oracle import OraclePolicy, OracleValue, set_threads
+    set_threads(min(16, len(os.sched_getaffinity(0))))
+    P, V = OraclePolicy(sds[0]), OracleValue(sds[1])
+    local, _ = generation
+    plies = 10
+    gids = [0, 77, 200, 341, 511]
+    prm = selfplay.search_params(rollouts=400, expand_thresh=100, noise_weight=0.25, sample_plies=8,
+                                 max_turns=80, prune=1, record_visits=1)     # exactly self_play()'s parameters
+    pool = selfplay.GamePool([20260 + g for g in gids], prm, cap=8192)
+    ev = selfplay.CallableEvaluator(P, V)
+    while min(pool.info(i)["n_moves"] for i in range(len(gids))) < plies:    # the games advance in lock-step
+        feats, npol = pool.collect()
+        assert len(feats) > 0
+        pool.deliver(*ev(feats, npol))
+    for i, g in enumerate(gids):
+        assert pool.moves(i)[:plies] == local["games"][g]["moves"][:plies], g
+        for ply in range(plies):
+            assert pool.visits(i, ply) == local["visits"][g][ply], (g, ply)
+    pool.close()
+
+
+def test_config4_f16x2_plays_the_same_generation(engine, generation):
+    """The opt-in f16x2 arithmetic: same engine, same seeds -> the same 512 games move for move."""
+    local, total = generation
+    engine.set_precision("f16x2")
+    try:
+        loc, tot = selfplay.self_play(selfplay.EngineEvaluator(engine), **CFG4)
+    finally:
+        engine.set_precision("f32")
+    same = sum(loc["games"][g]["moves"] == local["games"][g]["moves"] for g in range(512))
+    assert same == 512, same
+    assert tot["plies"] == total["plies"] and tot["black_wins"] == total["black_wins"]
+    assert engine.stats()["f16_overflow_fallbacks"] == 0
+
+
+def test_selfplay_records_reread_and_replayed(generation, tmp_path):
+    """f4: records written by a GPU generation (one SGF per game + games.json with per-ply root visit counts) are
+    read back with the SGF reader and replayed legally on a fresh board, to the same final score."""
+    local, _ = generation
+    gids = list(range(0, 512, 37))
+    selfplay.write_records(str(tmp_path), {g: local["games"][g] for g in gids}, {g: local["visits"][g] for g in gids})
+    rec = json.load(open(tmp_path / "games.json"))
+    assert sorted(map(int, rec)) == gids
+    for g in gids:
+        moves = rec[str(g)]["moves"]
+        assert moves == local["games"][g]["moves"]
+        assert go.get_moves(str(tmp_path / f"game_{g:05d}.sgf")) == moves
+        board = go.Game(moves=[])
+        for m in moves:
+            assert m == go.PASS or board.is_legal(m)
+            board.play_move(m)
+        assert board.area_score() == rec[str(g)]["score"]
+        vis = rec[str(g)]["visits"]
+        assert len(vis) == len(moves)
+        for ply, m in enumerate(moves[:-1]):
+            if m != go.PASS and vis[ply]:
+                v = {int(k): n for k, n in vis[ply].items()}
+                assert m in v and sum(v.values()) >= 300        # 400 rollouts/move, minus the root's own visits
+
+
+# ---- a6 / a11: the reference's policy playouts, seed-matched ------------------------------------------------------------
+class _OracleNet:
+    """policy_net(x[B,27,9,9]) -> logits, backed by the CPU oracle (the reference's arithmetic)."""
+
+    def __init__(self, sd):
+        from oracle.oracle import OraclePolicy
+        self.fn = OraclePolicy(sd)
+
+    def to(self, d):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, x):
+        return torch.from_numpy(self.fn(x.detach().cpu().numpy()))
+
+
+def test_policy_sample_legal_sample_playout_match_oracle_backed_net(sds):
+    """nnet.policy_sample (a6, nnet.py:286-297), selfplay.legal_sample / playout / policy_self_play (a11,
+    bin/selfplay.py:18-57): with the same torch seed the HIP net and an oracle-backed net draw the same moves."""
+    hip, ora = nnet.HipPolicyNet(sds[0]), _OracleNet(sds[0])
+    f = np.load(os.path.join(GOLDEN, "features.npz"))["incremental"].astype(np.float32)
+    for i in (0, 40, 200, 333, 500):
+        fts = torch.from_numpy(f[i])
+        for seed in (1, 2, 3):
+            torch.manual_seed(seed)
+            a = nnet.policy_sample(hip, None, fts=fts)
+            torch.manual_seed(seed)
+            b = nnet.policy_sample(ora, None, fts=fts)
+            assert a.dtype == torch.int64 and a.shape == () and int(a) == int(b)
+    game = go.Game(moves=[])
+    for seed in range(4):
+        torch.manual_seed(seed)
+        a = selfplay.legal_sample(hip, game)
+        torch.manual_seed(seed)
+        b = selfplay.legal_sample(ora, game)
+        assert int(a) == int(b) and game.is_legal(int(a))
+    # a position with few legal moves left: the descending-probability walk (selfplay.py:40-46) must agree too
+    res = {}
+    for name, net in (("hip", hip), ("oracle", ora)):
+        torch.manual_seed(11)
+        res[name] = selfplay.policy_self_play(net, net, 3)
+    assert res["hip"] == res["oracle"]
+    games, results = res["hip"]
+    assert len(games) == 3 and all(r in (1, -1) for r in results)
+    for mv in games:
+        assert 60 <= len(mv) <= 71                              # turn > 70 ends a playout (selfplay.py:16,22)
+        g = go.Game(moves=[])
+        for m in mv:
+            assert g.is_legal(m)
+            g.play_move(m)
+    hip.engine().close()
+
+
+# ---- f4: a reference-style .pt checkpoint through the launcher -----------------------------------------------------------
+def test_pt_checkpoint_through_launcher_to_engine(sds, tmp_path):
+    """boke.py:30-38's contract: torch.load(path)["model_state_dict"] -> load_state_dict -> eval.  Checkpoints written
+    in the reference's format load through the launcher's loader into the HIP nets (empty-board logits vs the
+    goldens), and `python -m bokego_amd.gtp -p x.pt -v y.pt -r N` answers a GTP session with them."""
+    from bokego_amd.gtp import load_state_dict
+    ppt, vpt = str(tmp_path / "policy.pt"), str(tmp_path / "value.pt")
+    torch.save({"model_state_dict": tensors_to_state_dict(sds[0]), "optimizer_state_dict": {}, "epoch": 19}, ppt)
+    torch.save({"model_state_dict": tensors_to_state_dict(sds[1])}, vpt)
+    pi = nnet.HipPolicyNet()
+    pi.load_state_dict(load_state_dict(ppt))
+    pi.eval()
+    v = nnet.HipValueNet()
+    v.load_state_dict(load_state_dict(vpt))
+    n = np.load(os.path.join(GOLDEN, "nets.npz"))
+    fts = nnet.features(go.Game())
+    assert fts.sum() == 531
+    lg = pi(fts.unsqueeze(0))
+    assert np.abs(lg.numpy()[0] - n["logits_b1"][0]).max() < 1e-4 and abs(lg[0, 40].item() - 12.709958) < 1e-4
+    assert abs(nnet.value(v, go.Game()) - float(n["values_b1"][0])) < 1e-4
+    d = nnet.policy_dist(pi, go.Game())
+    assert abs(d.probs[40].item() - 0.818645) < 1e-5
+    pi.engine().close(); v.engine().close()
+    session = "name\nkomi 7.5\nplay b e5\ngenmove w\nfinal_score\nmove_history\nquit\n"
+    for extra in ([], ["--python-tree"]):
+        out = subprocess.run([sys.executable, "-m", "bokego_amd.gtp", "-p", ppt, "-v", vpt, "-r", "200"] + extra,
+                             input=session, capture_output=True, text=True, timeout=300, cwd=REPO)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rep = out.stdout.split("\n\n")
+        assert rep[0] == "= boke" and rep[1] == "= " and rep[2] == "= "
+        assert rep[3] == "= G5"                                  # the reference's reply to E5 at 200 rollouts (gtp_transcript.json)
+        assert rep[4].startswith("= W+") or rep[4].startswith("= B+")
+        assert rep[5] == "= E5\nG5"

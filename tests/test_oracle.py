@@ -97,3 +97,24 @@ def test_torch_restatement_matches_reference(gold):
     h = np.load(os.path.join(GOLDEN, "hard_positions.npz"))
     lg, _, va = leaf_eval(P, V, torch.from_numpy(h["features"].astype(np.float32)))
     assert np.abs(lg.numpy() - h["logits"]).max() < TOL_LOGIT and np.abs(va.numpy() - h["values"]).max() < TOL_VALUE
+
+
+@pytest.mark.parametrize("wset", ["A", "B"])
+def test_sweep_worst_positions_both_weight_sets(wset):
+    """The oracle (C and torch restatements) on the sweep's worst positions, both weight sets: the second set pins the
+    restatements on weights they were not developed against."""
+    import torch
+    from oracle.torch_ref import TorchPolicy, TorchValue
+    w = np.load(os.path.join(GOLDEN, "sweep_worst.npz"))
+    p19, vs = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    if wset == "A":
+        pw, vw = p19, vs
+    else:
+        head_b = np.load(os.path.join(GOLDEN, "value_head_b.npz"))
+        pw, vw = {k: v for k, v in vs.items() if k.startswith("conv.")}, dict(p19)
+        vw.update({k: head_b[k] for k in head_b.files})
+    f = w[f"features_{wset}"].astype(np.float32)
+    assert np.abs(OraclePolicy(pw)(f) - w[f"logits_{wset}"]).max() < TOL_LOGIT
+    assert np.abs(OracleValue(vw)(f) - w[f"values_{wset}"]).max() < TOL_VALUE
+    assert np.abs(TorchPolicy(pw)(torch.from_numpy(f)).numpy() - w[f"logits_{wset}"]).max() < TOL_LOGIT
+    assert np.abs(TorchValue(vw)(torch.from_numpy(f)).numpy() - w[f"values_{wset}"]).max() < TOL_VALUE
