@@ -98,6 +98,7 @@ bool trunk_ok(const bk_trunk_weights& t) {
 // in bk_kernels.hip:
 //   index = (((tap*G + g)*4 + ntile)*64 + lane)*4 + j
 //   cout = 32*ntile + (lane&31), cin = 8g + 4(lane>>5) + j, tap = ky*K + kx
+//   (layer 0, g = 3: cin = 24 + 2j + (lane>>5) for j < 2, nothing for j >= 2: 27 channels in 14 k-steps of 2)
 void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
     wfrag.assign(BK_WFRAG_FLOATS + BK_WFRAG_PAD_FLOATS, 0.f);
     bias.assign(7 * 128, 0.f);
@@ -114,7 +115,10 @@ void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vecto
                 for (int nt = 0; nt < 4; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 4; ++j) {
-                            const int co = 32 * nt + (lane & 31), ci = 8 * g + 4 * (lane >> 5) + j;
+                            const int co = 32 * nt + (lane & 31);
+                            int ci = 8 * g + 4 * (lane >> 5) + j;
+                            // layer 0: the last group holds channels 24..26 in two k-steps (bk_kernels.hip in_slot())
+                            if (l == 0 && g == 3) ci = j < 2 ? 24 + 2 * j + (lane >> 5) : cin;
                             float v = 0.f;
                             if (ci < cin) v = (float)((double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co]);
                             wfrag[base + ((((size_t)tp * G + g) * 4 + nt) * 64 + lane) * 4 + j] = v;

@@ -7,9 +7,9 @@
 // network on them without leaving the CU:
 //   * the NB x 81 x 128 fp32 activations live in LDS, position-major, in a "shared halo"
 //     layout (10-column rows: the zero column between two board rows is the right halo of
-//     one and the left halo of the next, a zero row separates boards), so every 3x3 tap is a
-//     constant address offset and needs no bounds test; 16-byte chunks are XOR-swizzled by
-//     the position so the 32 rows of an MFMA A-fragment hit distinct LDS slots;
+//     one and the left halo of the next), so every 3x3 tap is a constant address offset and
+//     needs no bounds test; records are padded (528 B per position) so that the 16 lanes of a
+//     ds_read_b128 group hit 16 distinct LDS slots without any address swizzling;
 //   * each conv layer is an implicit GEMM  [32*MT rows] x [128 couts] x [taps*cin]  on the
 //     exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32; wave w owns couts 32w..32w+31 for
 //     ALL rows, so every weight is fetched by exactly one wave, straight from L2 into
@@ -53,29 +53,49 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 // ---- LDS layouts -------------------------------------------------------------------------
-// 128-channel activations: position p = (10*b + 1 + y)*10 + (x + 1); 512 B per position.
-__device__ __forceinline__ int pos3(int b, int y, int x) { return (10 * b + 1 + y) * 10 + x + 1; }
-// layer-0 input (27 channels padded to 32): 11-column rows with two shared halo columns,
-// two zero rows between boards (5x5 taps); 128 B per position.
-__device__ __forceinline__ int pos5(int b, int y, int x) { return (11 * b + 2 + y) * 11 + x + 2; }
-__device__ __forceinline__ int in_addr(int p, int c) { return p * 32 + ((((c >> 2) ^ ((p >> 1) & 7)) << 2) | (c & 3)); }
+// No XOR swizzle: every address the conv loops use is (per-lane base) + (compile-time constant), so the loops
+// contain NO vector-ALU address arithmetic (on this chip the fp32 MFMA shares the vector ALU: every VALU
+// instruction between two MFMAs is lost MFMA time).  Bank conflicts are avoided by PADDING instead.
+//
+// 128-channel activations: one record per position = 512 B of data + 16 B pad (REC3 = 528); a board row is 10
+// records (column 0 = the zero halo shared by the end of one row and the start of the next) at a pitch of
+// RP3 = 10*528 - 16: the never-touched pad of a row's last record overlaps the first 16 B of the next row's
+// halo record.  The 16-byte slot of chunk c of (row R, column C) is (9R + C + c) mod 16, so the 16 lanes of a
+// ds_read_b128 lane group -- 16 consecutive board points in (y,x) order -- read 16 distinct slots.
+// NB == 3: boards are stacked without separator rows (R = 1 + 9b + y): the only rows that could read across a
+// board edge are the y=0 / y=8 rows, which sit alone in tiles 0 / 7 and skip those taps (RowMap below).
+// NB < 3: a zero row after every board (R = 1 + 10b + y).
+constexpr int REC3 = 528, RP3 = 10 * REC3 - 16;
+// layer-0 input (27 channels in 32 slots = 128 B + 16 B pad, 5x5 taps): 11 records per row (columns 0,1 = halo),
+// pitch 1808 B (slot = (R + 9C + c) mod 16: consecutive points stay on distinct slots across row ends), two zero
+// rows on top; NB == 3: one zero row after every board (y=0 / y=8 rows skip their out-of-board taps), else two.
+constexpr int REC0 = 144, RP0 = 1808;
 
 template <int NB>
 struct Geo {
     static constexpr int MT = (81 * NB + 31) / 32;  // 32-row MFMA tiles in the workgroup
-    static constexpr int NPOS = 100 * NB + 11;      // positions in the 128-ch layout
-    static constexpr int NP0 = 121 * NB + 24;       // positions in the layer-0 layout
+    static constexpr int RB3 = NB == 3 ? 9 : 10, NROWS3 = 1 + NB * RB3;
+    static constexpr int RB0 = NB == 3 ? 10 : 11, NROWS0 = 2 + NB * RB0;
+    // + one record: the right-halo reads of the last row (column 10 resp. 11,12) land just behind it
+    static constexpr int L3_BYTES = NROWS3 * RP3 + REC3;
+    static constexpr int L0_BYTES = NROWS0 * RP0 + REC0;
+    static_assert(L0_BYTES <= L3_BYTES, "the layer-0 input lives inside the activation region");
     // the 4 waves form a WM x WN grid over [rows x couts]; a wave owns MTW row tiles x NT cout tiles.
-    // 2x2 halves the LDS reads per MFMA (an A fragment feeds NT MFMAs): on the fp32 MFMA every
-    // non-MFMA instruction costs issue time, so instructions per MFMA is what is minimised.
+    // 2x2 halves the LDS reads per MFMA (an A fragment feeds NT MFMAs).
     static constexpr int WM = (MT % 2 == 0) ? 2 : 1;
     static constexpr int WN = 4 / WM;
     static constexpr int NT = 4 / WN;
     static constexpr int MTW = MT / WM;
     static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one slot per thread)
     static constexpr int HS_FLOATS = NB * 96;
-    static constexpr int LDS_BYTES = (NPOS * 128 + DUMMY_FLOATS + HS_FLOATS) * 4;
+    static constexpr int LDS_BYTES = L3_BYTES + (DUMMY_FLOATS + HS_FLOATS) * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int addr3(int b, int y, int x) { return (1 + RB3 * b + y) * RP3 + (x + 1) * REC3; }  // bytes
+    static constexpr int addr0(int b, int y, int x) { return (2 + RB0 * b + y) * RP0 + (x + 2) * REC0; }
 };
+// float slot of input channel c inside a layer-0 record.  Channels 0..23 in order (groups 0..2 of 8); the last
+// group holds only 24..26 (+ one zero), arranged so that TWO k-steps cover it: chunk (6+h)[j] = channel 24+2j+h.
+__device__ __forceinline__ int in_slot(int c) { return c < 24 ? c : (6 + ((c - 24) & 1)) * 4 + ((c - 24) >> 1); }
 
 // Flat GEMM row r of the workgroup -> board point.  NB == 3 orders the rows y-major so that tile 0
 // holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding rows
@@ -96,28 +116,38 @@ struct RowMap {
     static constexpr int x(int r) {
         return !valid(r) ? 0 : NB == 3 ? (r < 32 ? r % 9 : r < 224 ? ((r - 32) % 63) % 9 : (r - 224) % 9) : (r % 81) % 9;
     }
-    static constexpr int flat(int r) { return 81 * b(r) + 9 * y(r) + x(r); }              // swizzle key source
-    static constexpr int pos(int r) { return (10 * b(r) + 1 + y(r)) * 10 + x(r) + 1; }   // 128-channel layout
+    static constexpr int addr3(int r) { return Geo<NB>::addr3(b(r), y(r), x(r)); }
 };
 
 // One conv layer for one wave: acc[mt][nt] (32 rows x 32 couts each) = sum over taps, cin.
 // wl: the layer's fragment-ordered weights [tap][group of 8 cin][cout tile (4)][lane][4].
+//
+// The K loop runs over taps (rolled); one tap = NBLK blocks of 4 channel groups (8 cin each), fully unrolled:
+//   A fragments  ds_read_b128 at (lane's tap pointer) + immediate (group*32 B); the tap pointers -- one per row
+//                tile -- advance by a wave-uniform delta once per tap: MTW vector adds per tap are the ONLY
+//                vector-ALU instructions besides the MFMAs;
+//   B fragments  buffer_load_dwordx4 with a scalar running offset (+4 KiB per group), lane offset constant:
+//                no vector address arithmetic, no 64-bit pointer carries;
+//   both software-pipelined through register ping-pong (A one group ahead, B one block ahead).
 template <int NB, bool FIRST>
-__device__ __forceinline__ void conv_layer(const float* act, const float* __restrict__ wl,
+__device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
                                            f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
-    constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
+    using G = Geo<NB>;
+    constexpr int MTW = G::MTW, NT = G::NT;
     constexpr int KW = FIRST ? 5 : 3;
     constexpr int TAPS = KW * KW;
-    constexpr int NBLK = FIRST ? 1 : 4;  // blocks of 4 channel-groups (8 cin each) per tap
+    constexpr int NBLK = FIRST ? 1 : 4;                 // blocks of 4 channel groups per tap
+    constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
     const int h = lane >> 5, l32 = lane & 31;
 
-    int pbase[MTW], rrow[MTW];
+    // per row tile: LDS pointer of this lane's row at tap (0,0), chunk h
+    const char* ap[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int r = (wm * MTW + mt) * 32 + l32;  // padding rows map to a valid point; never stored
         const int b = RowMap<NB>::b(r), y = RowMap<NB>::y(r), x = RowMap<NB>::x(r);
-        pbase[mt] = FIRST ? pos5(b, y, x) : pos3(b, y, x);
-        rrow[mt] = 81 * b + 9 * y + x;
+        const int a = FIRST ? G::addr0(b, y, x) - 2 * RP0 - 2 * REC0 : G::addr3(b, y, x) - RP3 - REC3;
+        ap[mt] = actb + a + h * 16;
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -126,166 +156,161 @@ __device__ __forceinline__ void conv_layer(const float* act, const float* __rest
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    // B fragments: block b (4 groups of 8 cin) of the layer is 16 KiB [group][cout tile][lane][4];
-    // this wave reads cout tiles wn*NT .. wn*NT+NT-1: NT coalesced 1 KiB loads per group, addressed
-    // as (wave-uniform base) + (lane offset) so the per-block pointer bump is scalar work.
-    const float* wv = wl + (wn * NT) * 256;
-    const int lane4 = lane * 4;
-    auto load_b = [&](f32x4 (&B)[4][NT], int blk) {
-        const float* wb = wv + (size_t)blk * 4096;
+    // B fragments: block b (4 groups of 8 cin) of the layer is 16 KiB [group][cout tile][lane][4]; this wave
+    // reads cout tiles wn*NT .. wn*NT+NT-1: NT coalesced 1 KiB loads per group.
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + (wn * NT) * 256), 0, 0x7ffffff0, 0x00020000);
+    const int lane16 = lane * 16;
+    int boff = 0;                                       // scalar: byte offset of the block being fetched
+    auto load_b = [&](f32x4 (&B)[4][NT]) {
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                B[gg][nt] = *reinterpret_cast<const f32x4*>(wb + (gg * 4 + nt) * 256 + lane4);
+                B[gg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16 + nt * 1024, boff + gg * 4096, 0));
+        boff += 16384;
+    };
+    auto read_a = [&](f32x4 (&A)[MTW], int imm) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + imm);
     };
 
-    // A fragments: byte address = abase + ((chunk<<4) ^ (swizzle<<4)): one v_xad_u32 per read.
-    const char* actb = reinterpret_cast<const char*>(act);
-    int ab[MTW], swb[MTW];
-    auto tap_setup = [&](int t) {
-        const int ky = t / KW, kx = t - ky * KW;
-        const int off = FIRST ? (ky - 2) * 11 + (kx - 2) : (ky - 1) * 10 + (kx - 1);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            const int pa = pbase[mt] + off;
-            ab[mt] = FIRST ? pa * 128 : pa * 512;
-            // swizzle key of the position being read = low bits of ITS flat index r + 9dy + dx (the
-            // writer's key): the 16 lanes of a ds_read_b128 group hit 16 distinct slots.  Out-of-board
-            // neighbours land in all-zero halo rows, where any key reads zeros.
-            swb[mt] = (FIRST ? ((pa >> 1) & 7) : ((rrow[mt] + 9 * (ky - 1) + (kx - 1)) & 15)) << 4;
-        }
-    };
-    const int hb = h << 4;
-    auto read_a = [&](f32x4 (&A)[MTW], int chunkb) {
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(actb + (ab[mt] + (chunkb ^ swb[mt])));
-    };
-
-    // Software pipeline, all through register ping-pong (no copies: on this chip the fp32 MFMA
-    // shares the vector ALU, so every extra VALU instruction in the loop is lost MFMA time):
-    //   group g+1's A fragments are read from LDS during group g's MFMAs,
-    //   block b+1's B fragments are fetched from L2 during block b's 128 MFMAs.
     f32x4 A0[MTW], A1[MTW], B0[4][NT], B1[4][NT];
-    constexpr int NBLOCKS = TAPS * NBLK;
 
-    // one block = 4 groups; `blk` is the block's index in the layer, Bc its fragments, Bn receives
-    // the next block's.  Group parity alternates A0/A1; a block has an even number of groups.
+    // One block = 4 groups.  Bc: its fragments, Bn receives the next block's.  Group parity alternates A0/A1.
+    // GB: the block's index inside its tap (compile time).  At the tap's last group the tap pointers move on
+    // (delta: wave-uniform) and the prefetch reads group 0 of the next tap.
     // MLO..MHI: the row tiles of this wave that take part (zero-halo tap skipping, see RowMap)
-    auto do_block = [&](auto MLO, auto MHI, int blk, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT]) {
-        constexpr int mlo = decltype(MLO)::value, mhi = decltype(MHI)::value;
-        load_b(Bn, blk + 1);  // the last block over-reads into the next layer / the pad: harmless
+    auto do_block = [&](auto MLO, auto MHI, auto GBc, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT], int delta) {
+        constexpr int mlo = decltype(MLO)::value, mhi = decltype(MHI)::value, gb = decltype(GBc)::value;
+        load_b(Bn);  // the layer's last block over-reads into the next layer / the pad: harmless
         __builtin_amdgcn_sched_barrier(0);
-        const int gb = NBLK == 1 ? 0 : (blk & (NBLK - 1));
-        const bool tap_end = gb == NBLK - 1;
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
             f32x4 (&Ac)[MTW] = (gg & 1) ? A1 : A0;
             f32x4 (&An)[MTW] = (gg & 1) ? A0 : A1;
-            int chunkb;
-            if (gg == 3) {
-                if (tap_end) {  // next group is group 0 of the next tap
-                    const int t = blk / NBLK;
-                    tap_setup(t + 1 < TAPS ? t + 1 : t);
-                    chunkb = hb;
-                } else {
-                    chunkb = ((gb * 4 + 4) << 5) | hb;
-                }
-            } else {
-                chunkb = ((gb * 4 + gg + 1) << 5) | hb;
-            }
+            // layer 0: the last channel group holds 4 channels (24..26 + a zero) packed into k-steps 0 and 1
+            constexpr int JN = 4;
+            const int jn = (FIRST && gg == 3) ? 2 : JN;
 #pragma unroll
             for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][0], Bc[gg][nt][0], acc[mt][nt], 0, 0, 0);
-            read_a(An, chunkb);
+            if (gg == 3 && gb == NBLK - 1) {   // next group is group 0 of the next tap
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) ap[mt] += delta;
+                read_a(An, 0);
+            } else {
+                read_a(An, (gb * 4 + gg + 1) * 32);
+            }
             __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued right after the first MFMA round
 #pragma unroll
-            for (int j = 1; j < 4; ++j)
+            for (int j = 1; j < JN; ++j) {
+                if (j < jn) {
 #pragma unroll
-                for (int mt = mlo; mt < mhi; ++mt)
+                    for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][j], Bc[gg][nt][j], acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][j], Bc[gg][nt][j], acc[mt][nt], 0, 0, 0);
+                }
+            }
         }
     };
 
-    // blocks [b0, b1), b0 even, with one tile range; the operand pipelines run across calls
-    auto run = [&](auto MLO, auto MHI, int b0, int b1) {
-#pragma unroll 1
-        for (int blk = b0; blk + 1 < b1; blk += 2) {
-            do_block(MLO, MHI, blk, B0, B1);
-            do_block(MLO, MHI, blk + 1, B1, B0);
-        }
-        if ((b1 - b0) & 1) do_block(MLO, MHI, b1 - 1, B0, B1);
-    };
-
-    load_b(B0, 0);
-    tap_setup(0);
-    read_a(A0, hb);
     using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
     using IM = std::integral_constant<int, MTW>;
-    if constexpr (NB == 3 && !FIRST) {
-        // 4 blocks per tap: ky=0 is blocks [0,12), ky=2 blocks [24,36)
-        if (wm == 0) {
-            run(std::integral_constant<int, 1>{}, IM{}, 0, 12);
-            run(I0{}, IM{}, 12, NBLOCKS);
+    // pointer delta from tap t to tap t+1 (0 after the layer's last tap: the final prefetch re-reads in place)
+    auto tap_delta = [&](int t) {
+        const int kx = t % KW;
+        return t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
+    };
+    // taps [t0, t1) with one tile range; the operand pipelines run across calls
+    auto run = [&](auto MLO, auto MHI, int t0, int t1) {
+        if constexpr (FIRST) {
+            // one block per tap: the B ping-pong alternates per tap, so two taps per iteration
+#pragma unroll 1
+            for (int t = t0; t + 1 < t1; t += 2) {
+                do_block(MLO, MHI, I0{}, B0, B1, tap_delta(t));
+                do_block(MLO, MHI, I0{}, B1, B0, tap_delta(t + 1));
+            }
         } else {
-            run(I0{}, IM{}, 0, 24);
-            run(I0{}, std::integral_constant<int, MTW - 1>{}, 24, NBLOCKS);
+#pragma unroll 1
+            for (int t = t0; t < t1; ++t) {
+                const int d = tap_delta(t);
+                do_block(MLO, MHI, I0{}, B0, B1, d);
+                do_block(MLO, MHI, I1{}, B1, B0, d);
+                do_block(MLO, MHI, I2{}, B0, B1, d);
+                do_block(MLO, MHI, I3{}, B1, B0, d);
+            }
+        }
+    };
+
+    load_b(B0);
+    read_a(A0, 0);
+    if constexpr (NB == 3 && !FIRST) {
+        // ky=0 is taps [0,3), ky=2 taps [6,9)
+        if (wm == 0) {
+            run(I1{}, IM{}, 0, 3);
+            run(I0{}, IM{}, 3, TAPS);
+        } else {
+            run(I0{}, IM{}, 0, 6);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 6, TAPS);
         }
     } else if constexpr (NB == 3 && FIRST) {
-        // 1 block per tap: ky=0,1 are blocks [0,10), ky=3,4 blocks [15,25); ranges start at even blocks
+        // ky=0,1 are taps [0,10), ky=3,4 taps [15,25); ranges of an even number of taps, the odd one out last
         if (wm == 0) {
-            run(std::integral_constant<int, 1>{}, IM{}, 0, 10);
-            run(I0{}, IM{}, 10, NBLOCKS);
+            run(I1{}, IM{}, 0, 10);
+            run(I0{}, IM{}, 10, 24);
+            do_block(I0{}, IM{}, I0{}, B0, B1, 0);
         } else {
             run(I0{}, IM{}, 0, 16);
-            run(I0{}, std::integral_constant<int, MTW - 1>{}, 16, NBLOCKS);
+            run(I0{}, std::integral_constant<int, MTW - 1>{}, 16, 24);
+            do_block(I0{}, std::integral_constant<int, MTW - 1>{}, I0{}, B0, B1, 0);
         }
+    } else if constexpr (FIRST) {
+        run(I0{}, IM{}, 0, 24);
+        do_block(I0{}, IM{}, I0{}, B0, B1, 0);
     } else {
-        run(I0{}, IM{}, 0, NBLOCKS);
+        run(I0{}, IM{}, 0, TAPS);
     }
 }
 
 // bias + ReLU + in-place store of this wave's tiles.  Accumulator register i of row tile T holds
 // row T*32 + (i&3) + 8*(i>>2) + 4*h (h = lane>>5): with the wave's row block WMI a template
-// constant both candidates are compile-time constants, so an address is two selects on h plus the
-// channel swizzle -- no table, no branches.  Rows beyond 81*NB (padding of the last tile) are
-// steered into a per-thread dummy slot.
+// constant both candidates are compile-time constants, so a byte address is (lane's column bytes) + (h ? P1 : P0)
+// -- no table, no branches.  Rows beyond 81*NB (padding of the last tile) are steered into a per-thread dummy slot.
 template <int NB, int WMI>
-__device__ __forceinline__ void store_tiles(float* act, int dummy_addr, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
+__device__ __forceinline__ void store_tiles(char* actb, int dummy_byte, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
                                             const float* __restrict__ bias, int col0, int h) {
     constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = col0 + 32 * nt;
         const float bv = bias[col];
-        const int cchunk = col >> 2, clow = col & 3;
+        const int colb = col * 4;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r0 = (WMI * MTW + mt) * 32 + (i & 3) + 8 * (i >> 2), r1 = r0 + 4;  // constants after unrolling
                 const bool ok0 = RowMap<NB>::valid(r0), ok1 = RowMap<NB>::valid(r1);
-                const int p0 = RowMap<NB>::pos(r0), p1 = RowMap<NB>::pos(r1);
-                const int k0 = RowMap<NB>::flat(r0) & 15, k1 = RowMap<NB>::flat(r1) & 15;
-                const int base = h ? p1 * 128 : p0 * 128;
-                const int swz = h ? k1 : k0;
-                int addr = base + (((cchunk ^ swz) << 2) | clow);
-                if (!(ok0 && ok1)) addr = (h ? ok1 : ok0) ? addr : dummy_addr;
+                const int p0 = RowMap<NB>::addr3(r0), p1 = RowMap<NB>::addr3(r1);
+                int addr = colb + (h ? p1 : p0);
+                if (!(ok0 && ok1)) addr = (h ? ok1 : ok0) ? addr : dummy_byte;
                 const float v = acc[mt][nt][i] + bv;
-                act[addr] = v > 0.f ? v : 0.f;
+                *reinterpret_cast<float*>(actb + addr) = v > 0.f ? v : 0.f;
             }
     }
 }
 
 template <int NB>
-__device__ __forceinline__ void store_layer(float* act, int dummy_addr, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
+__device__ __forceinline__ void store_layer(char* actb, int dummy_byte, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
                                             const float* __restrict__ bias, int wm, int col0, int h) {
-    if (Geo<NB>::WM == 1 || wm == 0) store_tiles<NB, 0>(act, dummy_addr, acc, bias, col0, h);
-    else store_tiles<NB, 1>(act, dummy_addr, acc, bias, col0, h);
+    if (Geo<NB>::WM == 1 || wm == 0) store_tiles<NB, 0>(actb, dummy_byte, acc, bias, col0, h);
+    else store_tiles<NB, 1>(actb, dummy_byte, acc, bias, col0, h);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -309,10 +334,10 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
         if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
     }
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* act = smem;
-    const int dummy_addr = G::NPOS * 128 + threadIdx.x;
-    float* hs = smem + G::NPOS * 128 + G::DUMMY_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* actb = smem;
+    const int dummy_byte = G::L3_BYTES + threadIdx.x * 4;
+    float* hs = reinterpret_cast<float*>(smem + G::L3_BYTES) + G::DUMMY_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -340,19 +365,20 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
 
     STAMP(0);
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
-    for (int i = tid; i < G::NP0 * 8; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < G::L0_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (a.feats_dtype == BK_FEATS_F32_) {
         const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
         for (int e = tid; e < nb * 2187; e += 256) {
             const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            act[in_addr(pos5(b, y, x), c)] = __builtin_nontemporal_load(X + e);  // streamed once: keep L2 for the weights
+            // streamed once: non-temporal, so the planes do not evict weight lines from L2
+            *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = __builtin_nontemporal_load(X + e);
         }
     } else {
         const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
         for (int e = tid; e < nb * 2187; e += 256) {
             const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            act[in_addr(pos5(b, y, x), c)] = (float)__builtin_nontemporal_load(X + e);
+            *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = (float)__builtin_nontemporal_load(X + e);
         }
     }
     __syncthreads();
@@ -363,14 +389,14 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     const int col0 = wn * (32 * G::NT) + (lane & 31);
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer<NB, true>(act, P.wfrag, acc, lane, wm, wn);
+    conv_layer<NB, true>(actb, P.wfrag, acc, lane, wm, wn);
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: clear it all (halo must be zero)
-    for (int i = tid; i < G::NPOS * 32; i += 256) reinterpret_cast<f32x4*>(act)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < G::L3_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     STAMP(3);
-    store_layer<NB>(act, dummy_addr, acc, P.bias, wm, col0, h);
+    store_layer<NB>(actb, dummy_byte, acc, P.bias, wm, col0, h);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -378,7 +404,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        conv_layer<NB, false>(act, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn);
+        conv_layer<NB, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
@@ -386,7 +412,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
         // hoisted out of this loop as loop invariants and live (spilled) across the MFMA loops
         int c0 = col0, hh = h;
         asm volatile("" : "+v"(c0), "+v"(hh));
-        store_layer<NB>(act, dummy_addr, acc, P.bias + L * 128, wm, c0, hh);
+        store_layer<NB>(actb, dummy_byte, acc, P.bias + L * 128, wm, c0, hh);
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
@@ -400,11 +426,12 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
             const int q = lane + 64 * k;
             float d = 0.f;
             if (q < 81) {
-                const int y = q / 9, x = q - 9 * y, p = pos3(wave, y, x);
+                const int y = q / 9, x = q - 9 * y;
+                const f32x4* rec = reinterpret_cast<const f32x4*>(actb + G::addr3(wave, y, x));
                 const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
 #pragma unroll 8
                 for (int cc = 0; cc < 32; ++cc) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(act + p * 128 + ((cc ^ ((81 * wave + q) & 15)) << 2));
+                    const f32x4 v = rec[cc];
                     const f32x4 w = hw[cc];
                     d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
                 }
