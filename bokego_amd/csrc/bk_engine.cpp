@@ -306,8 +306,8 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // workgroups (one per CU) followed by a tail launch whose workgroup size makes the partial last round
     // shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead of
     // 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.
-    const int nb1 = bk_pick_nb(a.B_policy, a.B_value, e->n_cu);
-    const long single = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu);
+    const int nb1 = bk_pick_nb(a.B_policy, a.B_value, e->n_cu, precision);
+    const long single = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu, precision);
     long best = single;
     int head_p = 0, head_v = 0, tail_nb = 0;
     const int full_p = a.B_policy / 3, full_v = a.B_value / 3;   // complete 3-board workgroups per net
@@ -319,9 +319,11 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
             if (hv > full_v) { hv = full_v; hp = (int)(head - hv); }
             const int rp = a.B_policy - 3 * hp, rv = a.B_value - 3 * hv;
             if (rp + rv == 0) break;
-            const int nbt = bk_pick_nb(rp, rv, e->n_cu);
-            const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, e->n_cu) + 4;  // + a second launch's overhead
-            if (cost < best && cost * 100 <= single * 97) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }  // worth >= 3 %
+            const int nbt = bk_pick_nb(rp, rv, e->n_cu, precision);
+            const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, e->n_cu, precision) + (precision == BK_PRECISION_F16X2 ? 4 : 1);  // + a second launch's overhead
+            // worth it from 3 % (f16x2: power-limited, the idle CUs of a ragged last round let the busy ones clock higher)
+            // resp. 1 % (fp32: issue-limited at full clock, a shorter last round is a shorter launch)
+            if (cost < best && cost * 100 <= single * (precision == BK_PRECISION_F16X2 ? 97 : 99)) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }
         }
     }
     if (tail_nb) {

@@ -66,7 +66,7 @@ struct bk_eval_args {
 // feature planes [B][27][9][9] u8 from B position records (bk_encode.hip)
 hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream);
 
-int bk_pick_nb(int B_policy, int B_value, int n_cu);
-long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu);  // modelled time of one launch (arbitrary units)
+int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision);
+long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision);  // modelled time of one launch (arbitrary units)
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

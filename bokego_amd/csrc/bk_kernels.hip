@@ -86,7 +86,7 @@ struct Geo {
     static constexpr int WN = 4 / WM;
     static constexpr int NT = 4 / WN;
     static constexpr int MTW = MT / WM;
-    static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one slot per thread)
+    static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one shared record: never read)
     static constexpr int HS_FLOATS = NB * 96;
     static constexpr int LDS_BYTES = L3_BYTES + (DUMMY_FLOATS + HS_FLOATS) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -129,26 +129,20 @@ struct RowMap {
 //   B fragments  buffer_load_dwordx4 with a scalar running offset (+4 KiB per group), lane offset constant:
 //                no vector address arithmetic, no 64-bit pointer carries;
 //   both software-pipelined through register ping-pong (A one group ahead, B one block ahead).
+// rowa[mt]: byte offset of this lane's row of tile mt at tap (0,0), chunk h (RowAddr below; computed once per kernel).
 template <int NB, bool FIRST>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
-                                           f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn) {
+                                           f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn,
+                                           const int (&rowa)[Geo<NB>::MTW]) {
     using G = Geo<NB>;
     constexpr int MTW = G::MTW, NT = G::NT;
     constexpr int KW = FIRST ? 5 : 3;
     constexpr int TAPS = KW * KW;
     constexpr int NBLK = FIRST ? 1 : 4;                 // blocks of 4 channel groups per tap
     constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
-    const int h = lane >> 5, l32 = lane & 31;
-
-    // per row tile: LDS pointer of this lane's row at tap (0,0), chunk h
     const char* ap[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        const int r = (wm * MTW + mt) * 32 + l32;  // padding rows map to a valid point; never stored
-        const int b = RowMap<NB>::b(r), y = RowMap<NB>::y(r), x = RowMap<NB>::x(r);
-        const int a = FIRST ? G::addr0(b, y, x) - 2 * RP0 - 2 * REC0 : G::addr3(b, y, x) - RP3 - REC3;
-        ap[mt] = actb + a + h * 16;
-    }
+    for (int mt = 0; mt < MTW; ++mt) ap[mt] = actb + rowa[mt];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -195,7 +189,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
             for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][0], Bc[gg][nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bc[gg][nt][0], Ac[mt][0], acc[mt][nt], 0, 0, 0);
             if (gg == 3 && gb == NBLK - 1) {   // next group is group 0 of the next tap
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) ap[mt] += delta;
@@ -211,7 +205,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
                     for (int mt = mlo; mt < mhi; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[mt][j], Bc[gg][nt][j], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bc[gg][nt][j], Ac[mt][j], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
@@ -278,39 +272,40 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     }
 }
 
-// bias + ReLU + in-place store of this wave's tiles.  Accumulator register i of row tile T holds
-// row T*32 + (i&3) + 8*(i>>2) + 4*h (h = lane>>5): with the wave's row block WMI a template
-// constant both candidates are compile-time constants, so a byte address is (lane's column bytes) + (h ? P1 : P0)
-// -- no table, no branches.  Rows beyond 81*NB (padding of the last tile) are steered into a per-thread dummy slot.
-template <int NB, int WMI>
-__device__ __forceinline__ void store_tiles(char* actb, int dummy_byte, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
-                                            const float* __restrict__ bias, int col0, int h) {
+// bias + ReLU + in-place store of this wave's tiles.  The product is computed transposed (weights = A operand,
+// activations = B operand), so accumulator register 4q+e of (mt, nt) is cout 32*(wn*NT+nt) + 8q + 4h + e of THIS
+// lane's position (h = lane>>5): four consecutive couts per q = one 16-byte store at (the lane's record) +
+// (compile-time offset) -- no address arithmetic, 4 ds_write_b128 per tile, and the 16 lanes of a store group
+// write 16 distinct LDS slots.  Lanes whose row is padding (beyond 81*NB) store into a per-thread dummy record.
+template <int NB>
+struct Bias4 { f32x4 v[Geo<NB>::NT][4]; };
+// this lane's couts of a layer: bias[32*(wn*NT+nt) + 8q + 4h .. +3].  Issued BEFORE the layer's conv loop so that the
+// loads have long landed when the epilogue wants them.
+template <int NB>
+__device__ __forceinline__ void load_bias(Bias4<NB>& bv, const float* __restrict__ bias, int wn, int h) {
+#pragma unroll
+    for (int nt = 0; nt < Geo<NB>::NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv.v[nt][q] = *reinterpret_cast<const f32x4*>(bias + 32 * (wn * Geo<NB>::NT + nt) + 8 * q + 4 * h);
+}
+// storea[mt]: byte offset of this lane's record of tile mt + its cout block (RowAddr below); padding rows: the dummy record
+template <int NB>
+__device__ __forceinline__ void store_layer(char* actb, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], const Bias4<NB>& bv,
+                                            const int (&storea)[Geo<NB>::MTW]) {
     constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = col0 + 32 * nt;
-        const float bv = bias[col];
-        const int colb = col * 4;
+    for (int mt = 0; mt < MTW; ++mt) {
+        char* wp = actb + storea[mt];
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r0 = (WMI * MTW + mt) * 32 + (i & 3) + 8 * (i >> 2), r1 = r0 + 4;  // constants after unrolling
-                const bool ok0 = RowMap<NB>::valid(r0), ok1 = RowMap<NB>::valid(r1);
-                const int p0 = RowMap<NB>::addr3(r0), p1 = RowMap<NB>::addr3(r1);
-                int addr = colb + (h ? p1 : p0);
-                if (!(ok0 && ok1)) addr = (h ? ok1 : ok0) ? addr : dummy_byte;
-                const float v = acc[mt][nt][i] + bv;
-                *reinterpret_cast<float*>(actb + addr) = v > 0.f ? v : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mt][nt][4 * q + e] + bv.v[nt][q][e], 0.f);
+                *reinterpret_cast<f32x4*>(wp + (32 * nt + 8 * q) * 4) = v;
             }
     }
-}
-
-template <int NB>
-__device__ __forceinline__ void store_layer(char* actb, int dummy_byte, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT],
-                                            const float* __restrict__ bias, int wm, int col0, int h) {
-    if (Geo<NB>::WM == 1 || wm == 0) store_tiles<NB, 0>(actb, dummy_byte, acc, bias, col0, h);
-    else store_tiles<NB, 1>(actb, dummy_byte, acc, bias, col0, h);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -336,7 +331,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
-    const int dummy_byte = G::L3_BYTES + threadIdx.x * 4;
+    const int dummy_byte = G::L3_BYTES;
     float* hs = reinterpret_cast<float*>(smem + G::L3_BYTES) + G::DUMMY_FLOATS;
 
     const int tid = threadIdx.x;
@@ -365,20 +360,38 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
 
     STAMP(0);
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
-    for (int i = tid; i < G::L0_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    if (a.feats_dtype == BK_FEATS_F32_) {
-        const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
-        for (int e = tid; e < nb * 2187; e += 256) {
-            const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            // streamed once: non-temporal, so the planes do not evict weight lines from L2
-            *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = __builtin_nontemporal_load(X + e);
+    // every thread fetches its <= ceil(NB*2187/256) elements first (all loads in flight: the loop used to pay one
+    // global-memory latency per element), then scatters them; non-temporal: the planes are read once and must not
+    // evict weight lines from L2
+    {
+        constexpr int PER = (NB * 2187 + 255) / 256;
+        const int n = nb * 2187;
+        float v[PER];
+        if (a.feats_dtype == BK_FEATS_F32_) {
+            const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int e = tid + 256 * k;
+                v[k] = e < n ? __builtin_nontemporal_load(X + e) : 0.f;
+            }
+        } else {
+            const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int e = tid + 256 * k;
+                v[k] = e < n ? (float)__builtin_nontemporal_load(X + e) : 0.f;
+            }
         }
-    } else {
-        const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
-        for (int e = tid; e < nb * 2187; e += 256) {
-            const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-            *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = (float)__builtin_nontemporal_load(X + e);
+        // zero the layer-0 region (halo!) while the loads fly
+        for (int i = tid; i < G::L0_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + 256 * k;
+            if (e < n) {
+                const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
+                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
+            }
         }
     }
     __syncthreads();
@@ -386,17 +399,29 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     STAMP(1);
     f32x16 acc[G::MTW][G::NT];
     const int wm = wave / G::WN, wn = wave - wm * G::WN;
-    const int col0 = wn * (32 * G::NT) + (lane & 31);
+    // this lane's GEMM rows, decoded ONCE (the decode has divisions): LDS byte offsets for the A-fragment reads of
+    // layer 0 / layers 1..6 (tap (0,0), chunk h) and for the epilogue stores (record + this wave's cout block)
+    int rowa0[G::MTW], rowa3[G::MTW], storea[G::MTW];
+#pragma unroll
+    for (int mt = 0; mt < G::MTW; ++mt) {
+        const int r = (wm * G::MTW + mt) * 32 + (lane & 31);  // padding rows read a valid point and store to the dummy record
+        const int b = RowMap<NB>::b(r), y = RowMap<NB>::y(r), x = RowMap<NB>::x(r);
+        rowa0[mt] = G::addr0(b, y, x) - 2 * RP0 - 2 * REC0 + h * 16;
+        rowa3[mt] = G::addr3(b, y, x) - RP3 - REC3 + h * 16;
+        storea[mt] = RowMap<NB>::valid(r) ? G::addr3(b, y, x) + (wn * G::NT * 32 + 4 * h) * 4 : dummy_byte;
+    }
+    Bias4<NB> bv;
+    load_bias<NB>(bv, P.bias, wn, h);
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer<NB, true>(actb, P.wfrag, acc, lane, wm, wn);
+    conv_layer<NB, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0);
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: clear it all (halo must be zero)
     for (int i = tid; i < G::L3_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     STAMP(3);
-    store_layer<NB>(actb, dummy_byte, acc, P.bias, wm, col0, h);
+    store_layer<NB>(actb, acc, bv, storea);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -404,15 +429,12 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        conv_layer<NB, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn);
+        load_bias<NB>(bv, P.bias + L * 128, wn, h);
+        conv_layer<NB, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
-        // make the lane's column / half opaque per layer: otherwise the 256 store addresses are
-        // hoisted out of this loop as loop invariants and live (spilled) across the MFMA loops
-        int c0 = col0, hh = h;
-        asm volatile("" : "+v"(c0), "+v"(hh));
-        store_layer<NB>(actb, dummy_byte, acc, P.bias + L * 128, wm, c0, hh);
+        store_layer<NB>(actb, acc, bv, storea);
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
@@ -495,17 +517,19 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
 
 }  // namespace
 
-// Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is
-// (workgroup rounds over the CUs) x (32-row MFMA tiles per workgroup); NB=1 workgroups are small
-// enough (57 KB LDS) to sit two per CU but then share the pipes, so that buys nothing here.
-// measured time of one round (one workgroup per CU) of 1/2/3-board workgroups: 86 : 150 : 195 us
-long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu) {
-    static const int t[4] = {0, 44, 77, 100};
+// Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is (workgroup rounds over
+// the CUs) x (time of one round of nb-board workgroups, one per CU).  NB=1 workgroups are small enough to sit two per
+// CU but then share the pipes, so that buys nothing here.
+//   f16x2: measured round times 86 : 150 : 195 us
+//   fp32:  the MFMA count sets the time: 3 / 6 / 8 row tiles, the 3-board form skipping 8 % of its MFMAs (zero-halo
+//          taps): 0.41 : 0.82 : 1
+long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision) {
+    static const int t16[4] = {0, 44, 77, 100}, t32[4] = {0, 41, 82, 100};
     const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
-    return (wgs + n_cu - 1) / n_cu * t[nb];
+    return (wgs + n_cu - 1) / n_cu * (precision == BK_PRECISION_F16X2 ? t16 : t32)[nb];
 }
 
-int bk_pick_nb(int B_policy, int B_value, int n_cu) {
+int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
     if (const char* f = getenv("BK_FORCE_NB")) {
         const int v = atoi(f);
         if (v >= 1 && v <= 3) return v;
@@ -513,7 +537,7 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu) {
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
-        const long cost = bk_launch_cost(B_policy, B_value, nb, n_cu);
+        const long cost = bk_launch_cost(B_policy, B_value, nb, n_cu, precision);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;
