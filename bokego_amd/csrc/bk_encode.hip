@@ -7,183 +7,205 @@
 // the host (bk_pos_liberties / bk_pool_collect_pos run it before the record is copied); everything else is a
 // pure function of (board, libs, ko, last_move, turn) and is computed here.
 //
-// Mapping: one workgroup = one position, 128 threads, one thread per board point (81 active).  The workgroup
-// needs 2.8 KB of LDS and few registers on purpose: it is launched on the engine's copy-in stream, so it runs
-// *under* the previous request's leaf kernel, whose 3-board workgroups leave 4.6 KB of LDS per CU free.
-//   1. chains by label propagation in LDS (label = smallest point index of the chain, min over same-colour
-//      neighbours + pointer jumping, until no label changes);
-//   2. per chain: stone mask, neighbour mask (96-bit, three LDS words) and size, by LDS atomics;
+// Mapping: one workgroup = THREE positions, 256 threads, one thread per board point (243 active) -- the same 3-board
+// packing as the leaf kernel.  No LDS atomics, no data-dependent workgroup barriers (two fixed ones):
+//   1. bitboards.  Every wave ballots "black here" / "white here"; each thread then cuts its position's 81 bits out
+//      of the workgroup's 256-bit ballots as three 27-bit words (3 board rows per word: +-9 is a shift by 9 with a
+//      carry between words, +-1 a shift by 1 under a column mask);
+//   2. chains by flood fill IN REGISTERS: a stone's thread grows its own chain from its own bit
+//      (x |= dilate(x) & own_colour until nothing changes; the loop is wave-uniform via __any) and publishes
+//      {chain mask, the chain's single liberty or none} as one 16-byte LDS record;
 //   3. per empty point: the move's captures / new-chain liberties as mask operations on the <= 4 neighbouring
-//      chains (the same algebra as features_impl in bk_go.cpp, including the reference's per-touching-point
-//      double count of captured chains, go.py:413-416);
+//      chains' records (the same algebra as features_impl in bk_go.cpp, including the reference's
+//      per-touching-point double count of captured chains, go.py:413-416);
 //   4. 27 byte planes per position, written plane-major ([27][81], coalesced over the points).
-// Integer/byte work: HBM-bound by 192 B in + 2,187 B out per position; no MFMA.
+// Integer/byte work: HBM-bound by 192 B in + 2,187 B out per position; no MFMA.  4 KB of LDS and < 64 VGPRs per
+// workgroup, so it still fits beside the leaf kernel's 3-board workgroups when launched on the copy-in stream.
 #include "bk_internal.h"
+
+#ifndef BK_ENC_EXP
+#define BK_ENC_EXP 0   // timing experiments only (wrong results): 1 = one plane stored, 2 = one flood round
+#endif
 
 namespace {
 
 constexpr int NN = 81;
+constexpr int PPW = 3;                    // positions per workgroup
+constexpr unsigned M27 = 0x7FFFFFFu;      // one word = 3 board rows
+constexpr unsigned NC0 = 0x1FEu | (0x1FEu << 9) | (0x1FEu << 18);  // points whose column is not 0
+constexpr unsigned NC8 = 0x0FFu | (0x0FFu << 9) | (0x0FFu << 18);  // points whose column is not 8
 
-struct Mask {
+struct BB {  // 81-point set: word k = rows 3k..3k+2, bit = 9*(row%3) + col
     unsigned w[3];
 };
-
-__device__ __forceinline__ void mask_set(Mask& m, int s) {  // no dynamic register indexing
-    const unsigned bit = 1u << (s & 31);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) m.w[i] |= (s >> 5) == i ? bit : 0u;
+__device__ __forceinline__ BB operator|(BB a, BB b) { return {{a.w[0] | b.w[0], a.w[1] | b.w[1], a.w[2] | b.w[2]}}; }
+__device__ __forceinline__ BB operator&(BB a, BB b) { return {{a.w[0] & b.w[0], a.w[1] & b.w[1], a.w[2] & b.w[2]}}; }
+__device__ __forceinline__ BB operator~(BB a) { return {{~a.w[0] & M27, ~a.w[1] & M27, ~a.w[2] & M27}}; }
+__device__ __forceinline__ bool operator!=(BB a, BB b) { return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2])) != 0; }
+__device__ __forceinline__ int popc(BB a) { return __popc(a.w[0]) + __popc(a.w[1]) + __popc(a.w[2]); }
+// all points adjacent to a point of x (go.py:375-383)
+__device__ __forceinline__ BB dilate(BB x) {
+    BB d;
+    d.w[0] = ((x.w[0] << 9) & M27) | (x.w[0] >> 9) | ((x.w[1] << 18) & M27) | ((x.w[0] << 1) & NC0) | ((x.w[0] >> 1) & NC8);
+    d.w[1] = ((x.w[1] << 9) & M27) | (x.w[0] >> 18) | (x.w[1] >> 9) | ((x.w[2] << 18) & M27) | ((x.w[1] << 1) & NC0) | ((x.w[1] >> 1) & NC8);
+    d.w[2] = ((x.w[2] << 9) & M27) | (x.w[1] >> 18) | (x.w[2] >> 9) | ((x.w[2] << 1) & NC0) | ((x.w[2] >> 1) & NC8);
+    return d;
 }
-__device__ __forceinline__ int mask_pop(const Mask& m) { return __popc(m.w[0]) + __popc(m.w[1]) + __popc(m.w[2]); }
+__device__ __forceinline__ BB single(int k, unsigned bit) {  // no dynamic register indexing
+    return {{k == 0 ? bit : 0u, k == 1 ? bit : 0u, k == 2 ? bit : 0u}};
+}
+__device__ __forceinline__ unsigned word_of(BB a, int k) { return k == 0 ? a.w[0] : k == 1 ? a.w[1] : a.w[2]; }
 
-struct PosLds {
-    signed char board[84];
-    unsigned char libs[84];
-    int label[NN];
-    unsigned stones[NN][3];
-    unsigned nbrs[NN][3];
-    int size[NN];
-    unsigned empty[3];
-    int ko, last_move, turn;
+struct EncLds {
+    unsigned bal[2][8];          // black / white ballots of the 4 waves = 256 bits each
+    uint4 chain[PPW][NN];        // per stone: its chain's mask (x,y,z) and the chain's only liberty (w; 255: not exactly one)
 };
 
-__global__ void __launch_bounds__(128) bk_encode_kernel(const unsigned char* __restrict__ pos, int B,
+__global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __restrict__ pos, int B,
                                                        unsigned char* __restrict__ planes) {
-    __shared__ PosLds P;
-    const int q = threadIdx.x;          // board point (lanes 81..127 idle, they only take part in the barriers)
-    const int b = blockIdx.x;
-    const bool live = q < NN && b < B;
+    __shared__ EncLds S;
+    const int tid = threadIdx.x;
+    const int p = tid / NN;              // position inside the workgroup (3: the 13 spare threads)
+    const int q = tid - NN * p;          // board point
+    const int b = blockIdx.x * PPW + p;
+    const bool live = p < PPW && b < B;
     const int r = q / 9, c = q - 9 * r;
+    const int k = r / 3;                 // bitboard word and bit of this point
+    const unsigned bit = 1u << (q - 27 * k);
 
-    // neighbours (go.py:375-383 order is irrelevant here: only sums / unions are formed); fixed slots with a
-    // validity mask so that nothing is indexed dynamically
-    const int nb[4] = {q + 9, q - 9, q + 1, q - 1};
-    const bool nv[4] = {r + 1 < 9, r >= 1, c + 1 < 9, c >= 1};
-    constexpr int nn = 4;
-
-    int me_board = 0, my_libs = 0;
+    int me_board = 0, my_libs = 0, ko = -1, last_move = -3, turn = 0;
     if (live) {
-        const unsigned char* src = pos + (size_t)b * 192;
+        const unsigned char* src = pos + (size_t)b * BK_POS_BYTES;
         me_board = (signed char)src[q];
         my_libs = src[81 + q];
-        P.board[q] = (signed char)me_board;
-        P.libs[q] = (unsigned char)my_libs;
-        P.label[q] = me_board ? q : -1;
-        P.stones[q][0] = P.stones[q][1] = P.stones[q][2] = 0;
-        P.nbrs[q][0] = P.nbrs[q][1] = P.nbrs[q][2] = 0;
-        P.size[q] = 0;
-        if (q < 3) P.empty[q] = 0;
-        if (q == 0) {
-            P.ko = (short)(src[164] | (src[165] << 8));
-            P.last_move = (short)(src[166] | (src[167] << 8));
-            P.turn = (int)(src[172] | (src[173] << 8) | (src[174] << 16) | ((unsigned)src[175] << 24));
+        const unsigned kl = *reinterpret_cast<const unsigned*>(src + 164);   // ko | last_move << 16 (records are 192-B aligned)
+        ko = (short)(kl & 0xffffu);
+        last_move = (short)(kl >> 16);
+        turn = *reinterpret_cast<const int*>(src + 172);
+    }
+    // ---- 1. bitboards from wave ballots ----
+    const unsigned long long bb = __ballot(me_board == 1), bw = __ballot(me_board == 2);
+    if ((tid & 63) == 0) {
+        const int w = tid >> 6;
+        S.bal[0][2 * w] = (unsigned)bb; S.bal[0][2 * w + 1] = (unsigned)(bb >> 32);
+        S.bal[1][2 * w] = (unsigned)bw; S.bal[1][2 * w + 1] = (unsigned)(bw >> 32);
+    }
+    __syncthreads();
+    BB black, white;
+    {
+        const int pp = p < PPW ? p : 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int off = NN * pp + 27 * kk, i = off >> 5, sh = off & 31;     // off + 27 <= 243: i + 1 <= 7
+            const unsigned long long b2 = ((unsigned long long)S.bal[0][i + 1] << 32) | S.bal[0][i];
+            const unsigned long long w2 = ((unsigned long long)S.bal[1][i + 1] << 32) | S.bal[1][i];
+            black.w[kk] = (unsigned)(b2 >> sh) & M27;
+            white.w[kk] = (unsigned)(w2 >> sh) & M27;
+        }
+    }
+    const BB empty = ~(black | white);
+
+    // ---- 2. this stone's chain, grown in registers ----
+    const BB seed = single(k, bit);
+    BB x = seed;
+    {
+        const BB own = me_board == 1 ? black : white;
+        bool changed = live && me_board != 0;
+        while (__any(changed)) {           // wave-uniform: at most 81 rounds, normally a handful
+            const BB nx = (x | dilate(x)) & own;
+            changed = changed && (nx != x);
+            if (changed) x = nx;
+#if BK_ENC_EXP == 2
+            break;
+#endif
+        }
+        if (live && me_board != 0) {
+            const BB lib = dilate(x) & empty;
+            unsigned only = 255u;
+            if (popc(lib) == 1)
+                only = lib.w[0] ? __ffs(lib.w[0]) - 1 : lib.w[1] ? 27 + __ffs(lib.w[1]) - 1 : 54 + __ffs(lib.w[2]) - 1;
+            S.chain[p][q] = make_uint4(x.w[0], x.w[1], x.w[2], only);
         }
     }
     __syncthreads();
 
-    // ---- 1. chain labels ----
-    for (;;) {
-        int changed = 0;
-        if (live && me_board) {
-            int m = P.label[q];
-#pragma unroll
-            for (int k = 0; k < nn; ++k)
-                if (nv[k] && P.board[nb[k]] == me_board) m = min(m, P.label[nb[k]]);
-            m = min(m, P.label[m]);  // pointer jumping: labels only ever point to smaller indices of the same chain
-            if (m < P.label[q]) { P.label[q] = m; changed = 1; }
-        }
-        // racy reads of neighbouring labels only ever see values that are valid (smaller-or-equal, same chain)
-        if (!__syncthreads_or(changed)) break;
-    }
-
-    // ---- 2. per-chain masks ----
-    if (live) {
-        if (me_board) {
-            const int g = P.label[q];
-            atomicOr(&P.stones[g][q >> 5], 1u << (q & 31));
-#pragma unroll
-            for (int k = 0; k < nn; ++k)
-                if (nv[k]) atomicOr(&P.nbrs[g][nb[k] >> 5], 1u << (nb[k] & 31));
-            atomicAdd(&P.size[g], 1);
-        } else {
-            atomicOr(&P.empty[q >> 5], 1u << (q & 31));
-        }
-    }
-    __syncthreads();
-
-    // ---- 3/4. planes ----
-    if (!live) return;
-    unsigned char* out = planes + (size_t)b * 2187 + q;
-    const int me = (P.turn & 1) ? 2 : 1, opp = 3 - me;
+    // ---- 3. this point's 27 plane values ----
     unsigned char v[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) v[i] = 0;
-    if (me_board == me) v[0] = 1;
-    else if (me_board != 0) v[1] = 1;
-    else v[2] = 1;
-    if (me == 1) v[3] = 1;
-    if (q == P.last_move) v[4] = 1;
-    int p_lib = -1, lib_val = 0, p_la = -1, la_val = 0, p_cap = -1, cap_val = 0;
-    if (my_libs) { p_lib = 6 + (my_libs > 6 ? 6 : my_libs - 1); lib_val = my_libs > 6 ? 7 : my_libs; }
-    bool legal = false;
-    if (me_board == 0 && q != P.ko) {
-        Mask nbm{{0, 0, 0}}, lib{{0, 0, 0}}, cap{{0, 0, 0}};
+    if (live) {
+        const int nb[4] = {q + 9, q - 9, q + 1, q - 1};
+        const bool nv[4] = {r + 1 < 9, r >= 1, c + 1 < 9, c >= 1};
+        const int me = (turn & 1) ? 2 : 1, opp = 3 - me;
+        if (me_board == me) v[0] = 1;
+        else if (me_board != 0) v[1] = 1;
+        else v[2] = 1;
+        if (me == 1) v[3] = 1;
+        if (q == last_move) v[4] = 1;
+        int p_lib = -1, lib_val = 0, p_la = -1, la_val = 0, p_cap = -1, cap_val = 0;
+        if (my_libs) { p_lib = 6 + (my_libs > 6 ? 6 : my_libs - 1); lib_val = my_libs > 6 ? 7 : my_libs; }
+        bool legal = false;
+        if (me_board == 0 && q != ko) {
+            BB newchain = seed, cap{{0, 0, 0}};
+            int cap_dup = 0;
 #pragma unroll
-        for (int k = 0; k < nn; ++k)
-            if (nv[k]) mask_set(nbm, nb[k]);
-        for (int i = 0; i < 3; ++i) lib.w[i] = nbm.w[i] & P.empty[i];
-        Mask chain_nbrs = nbm;
-        int cap_dup = 0;
-#pragma unroll
-        for (int k = 0; k < nn; ++k) {
-            if (!nv[k]) continue;
-            const int t = nb[k], bt = P.board[t];
-            if (bt == 0) continue;
-            const int g = P.label[t];
-            if (bt == opp) {
-                // captured iff the chain's only liberty is this point
-                Mask gl;
-                for (int i = 0; i < 3; ++i) gl.w[i] = P.nbrs[g][i] & P.empty[i];
-                bool only_me = true;
-                for (int i = 0; i < 3; ++i) only_me &= gl.w[i] == ((q >> 5) == i ? 1u << (q & 31) : 0u);
-                if (only_me) {
-                    for (int i = 0; i < 3; ++i) cap.w[i] |= P.stones[g][i];
-                    cap_dup += P.size[g];
-                }
-            } else {
-                for (int i = 0; i < 3; ++i) {
-                    chain_nbrs.w[i] |= P.nbrs[g][i];
-                    lib.w[i] |= P.nbrs[g][i] & P.empty[i];
+            for (int j = 0; j < 4; ++j) {
+                if (!nv[j]) continue;
+                const int t = nb[j], tk = t / 27;
+                const unsigned tb = 1u << (t - 27 * tk);
+                const int bt = (word_of(black, tk) & tb) ? 1 : (word_of(white, tk) & tb) ? 2 : 0;
+                if (bt == 0) continue;
+                const uint4 ch = S.chain[p][t];
+                const BB cx{{ch.x, ch.y, ch.z}};
+                if (bt == opp) {
+                    if (ch.w == (unsigned)q) {   // captured iff the chain's only liberty is this point
+                        cap = cap | cx;
+                        cap_dup += popc(cx);     // once per touching point, as the reference counts (go.py:413-416)
+                    }
+                } else {
+                    newchain = newchain | cx;
                 }
             }
+            const BB d = dilate(newchain);
+            const BB lib = (d & empty & ~seed) | (cap & d);
+            const int la = popc(lib);
+            if (la) {  // la == 0: suicide
+                legal = true;
+                p_la = 13 + (la > 6 ? 6 : la - 1);
+                la_val = la > 6 ? 7 : la;
+                if (cap_dup) { p_cap = 20 + (cap_dup > 6 ? 6 : cap_dup - 1); cap_val = cap_dup > 6 ? 7 : cap_dup; }
+            }
         }
-        for (int i = 0; i < 3; ++i) {
-            const unsigned mebit = (q >> 5) == i ? 1u << (q & 31) : 0u;
-            lib.w[i] = (lib.w[i] & ~mebit) | (cap.w[i] & chain_nbrs.w[i]);
-        }
-        const int la = mask_pop(lib);
-        if (la) {  // la == 0: suicide
-            legal = true;
-            p_la = 13 + (la > 6 ? 6 : la - 1);
-            la_val = la > 6 ? 7 : la;
-            if (cap_dup) { p_cap = 20 + (cap_dup > 6 ? 6 : cap_dup - 1); cap_val = cap_dup > 6 ? 7 : cap_dup; }
+        if (legal) v[5] = 1;
+#pragma unroll
+        for (int i = 6; i < 27; ++i) {
+            if (i == p_lib) v[i] = (unsigned char)lib_val;
+            if (i == p_la) v[i] = (unsigned char)la_val;
+            if (i == p_cap) v[i] = (unsigned char)cap_val;
         }
     }
-    if (legal) v[5] = 1;
+
+    // ---- 4. planes out, plane-major: one byte per point and plane (a wave's store covers 64 consecutive bytes).
+    //         Measured alternatives, both slower: staging the planes in LDS and writing aligned 16-byte chunks, one
+    //         position per round in 4 KB (14.7 us per 4,096 positions) or all three at once in 6.6 KB (14.6 us), against
+    //         13.0 us for these direct byte stores (the 27 ds_write_b8 + barriers cost more than the 27 store instructions).
+    if (live) {
+        unsigned char* out = planes + (size_t)b * 2187 + q;
 #pragma unroll
-    for (int i = 6; i < 27; ++i) {
-        if (i == p_lib) v[i] = (unsigned char)lib_val;
-        if (i == p_la) v[i] = (unsigned char)la_val;
-        if (i == p_cap) v[i] = (unsigned char)cap_val;
+        for (int i = 0; i < 27; ++i) {
+#if BK_ENC_EXP == 1
+            if (i > 0) break;   // experiment: one plane only
+#endif
+            out[i * NN] = v[i];
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 27; ++i) out[i * NN] = v[i];
 }
 
 }  // namespace
 
 hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bk_encode_kernel, dim3(B), dim3(128), 0, stream, static_cast<const unsigned char*>(d_pos), B,
+    hipLaunchKernelGGL(bk_encode_kernel, dim3((B + PPW - 1) / PPW), dim3(256), 0, stream, static_cast<const unsigned char*>(d_pos), B,
                        d_planes);
     return hipGetLastError();
 }
