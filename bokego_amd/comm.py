@@ -23,6 +23,7 @@ COMM_SYMBOLS = {
     "bk_comm_unique_id": (ctypes.c_int, [_VP]),
     "bk_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, ctypes.POINTER(_VP)]),
     "bk_comm_allreduce_sum_f64": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
+    "bk_comm_broadcast_f32": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int]),
     "bk_comm_rank": (ctypes.c_int, [_VP]),
     "bk_comm_world": (ctypes.c_int, [_VP]),
     "bk_comm_destroy": (ctypes.c_int, [_VP]),
@@ -118,6 +119,13 @@ class NativeComm:
         a = np.ascontiguousarray(vec, np.float64).copy()
         if self._lib.bk_comm_allreduce_sum_f64(self._h, a.ctypes.data, a.size):
             raise RuntimeError("bk_comm_allreduce_sum_f64: " + self._lib.bk_comm_last_error().decode())
+        return a
+
+    def broadcast_f32(self, vec, root=0):
+        """rank `root`'s float32 vector to every rank (in place on a contiguous array; returns it)."""
+        a = np.ascontiguousarray(vec, np.float32)
+        if self._lib.bk_comm_broadcast_f32(self._h, a.ctypes.data, a.size, int(root)):
+            raise RuntimeError("bk_comm_broadcast_f32: " + self._lib.bk_comm_last_error().decode())
         return a
 
     def close(self):

@@ -15,6 +15,8 @@ struct bk_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double* d_buf = nullptr;
+    float* d_bc = nullptr;       // broadcast staging, grown on demand
+    size_t bc_bytes = 0;
     int rank = 0, world = 1, device = 0;
 };
 
@@ -88,6 +90,26 @@ int bk_comm_allreduce_sum_f64(bk_comm* c, double* buf, int n) {
     return 0;
 }
 
+int bk_comm_broadcast_f32(bk_comm* c, float* buf, int64_t n, int root) {
+    if (!c || !buf) return fail("comm or buf is NULL");
+    if (n < 0 || root < 0 || root >= c->world) return fail("bad n or root");
+    if (n == 0) return 0;
+    TRY_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * sizeof(float);
+    if (bytes > c->bc_bytes) {
+        if (c->d_bc) (void)hipFree(c->d_bc);
+        c->d_bc = nullptr;
+        c->bc_bytes = 0;
+        TRY_HIP(hipMalloc((void**)&c->d_bc, bytes));
+        c->bc_bytes = bytes;
+    }
+    if (c->rank == root) TRY_HIP(hipMemcpyAsync(c->d_bc, buf, bytes, hipMemcpyHostToDevice, c->stream));
+    TRY_NCCL(ncclBroadcast(c->d_bc, c->d_bc, (size_t)n, ncclFloat, root, c->comm, c->stream));
+    if (c->rank != root) TRY_HIP(hipMemcpyAsync(buf, c->d_bc, bytes, hipMemcpyDeviceToHost, c->stream));
+    TRY_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int bk_comm_rank(const bk_comm* c) { return c ? c->rank : -1; }
 int bk_comm_world(const bk_comm* c) { return c ? c->world : -1; }
 
@@ -97,6 +119,7 @@ int bk_comm_destroy(bk_comm* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->d_bc) (void)hipFree(c->d_bc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;

@@ -285,6 +285,38 @@ def all_reduce_stats(stats, device=None, native_comm=None):
     return t.cpu().numpy(), time.perf_counter() - t0
 
 
+def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None):
+    """Generation start (optional): every rank gets rank `src`'s PolicyNet / ValueNet tensors -- one
+    broadcast of the two nets' tensors packed back to back (2 x 3.9 MB), through torch.distributed (RCCL on GPUs, gloo
+    in the CPU tests) or libbkcomm.so.  Returns (policy_sd, value_sd) as ordered dicts of float32 arrays with the
+    caller's names and shapes; without a process group / communicator the inputs come back unchanged.  The reference
+    shares its weights between worker processes with share_memory() instead (bin/selfplay.py:171-175)."""
+    from collections import OrderedDict
+    sds = [OrderedDict((k, np.ascontiguousarray(np.asarray(v.detach().cpu() if hasattr(v, "detach") else v), np.float32))
+                       for k, v in sd.items() if not k.endswith("num_batches_tracked")) for sd in (policy_sd, value_sd)]
+    flat = np.concatenate([a.reshape(-1) for sd in sds for a in sd.values()])
+    if native_comm is not None:
+        flat = native_comm.broadcast_f32(flat, src)
+    else:
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return sds[0], sds[1]
+        t = torch.from_numpy(flat)
+        if device is not None:
+            t = t.to(device)
+        dist.broadcast(t, src=src)
+        flat = t.cpu().numpy()
+    out, at = [], 0
+    for sd in sds:
+        o = OrderedDict()
+        for k, a in sd.items():
+            o[k] = flat[at:at + a.size].reshape(a.shape).copy()
+            at += a.size
+        out.append(o)
+    return out[0], out[1]
+
+
 def shard_game_ids(n_games, rank, world):
     return [g for g in range(n_games) if g % world == rank]
 

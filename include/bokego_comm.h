@@ -33,6 +33,10 @@ int bk_comm_unique_id(uint8_t id[BK_COMM_ID_BYTES]);
 int bk_comm_init(int rank, int world, const uint8_t id[BK_COMM_ID_BYTES], int device_id, bk_comm **out);
 /* in-place sum over all ranks of a host fp64 vector (n <= 4096): one ncclAllReduce on the comm's stream */
 int bk_comm_allreduce_sum_f64(bk_comm *c, double *buf, int n);
+/* generation start (optional): rank `root`'s n fp32 values -- a net's tensors back to back, 2 x 3.9 MB for
+ * both nets -- to every rank, in place: one ncclBroadcast through a device buffer grown on demand.  The reference
+ * shares weights between its worker processes with share_memory() (bin/selfplay.py:171-175). */
+int bk_comm_broadcast_f32(bk_comm *c, float *buf, int64_t n, int root);
 int bk_comm_rank(const bk_comm *c);
 int bk_comm_world(const bk_comm *c);
 int bk_comm_destroy(bk_comm *c);

@@ -20,6 +20,26 @@ def test_native_allreduce_world1(tmp_path):
     c.close()
 
 
+def test_native_broadcast_world1_and_python_wrapper(tmp_path):
+    """bk_comm_broadcast_f32 (RCCL ncclBroadcast through a device buffer) and selfplay.broadcast_weights on a
+    one-rank communicator: 2 x 3.9 MB of weights make the round trip through the GPU unchanged."""
+    import os
+    from bokego_amd import selfplay
+    from bokego_amd.bkw import load_bkw
+    from conftest import GOLDEN
+    c = comm.NativeComm.create(0, 1, 0, str(tmp_path / "id"))
+    v = np.random.default_rng(1).standard_normal(100_003).astype(np.float32)
+    assert np.array_equal(c.broadcast_f32(v.copy()), v)
+    with pytest.raises(RuntimeError):
+        c.broadcast_f32(v, root=1)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    bp, bv = selfplay.broadcast_weights(pw, vw, native_comm=c)
+    assert list(bp) == list(pw) and list(bv) == list(vw)
+    assert all(np.array_equal(bp[k], pw[k]) and bp[k].shape == pw[k].shape for k in pw)
+    assert all(np.array_equal(bv[k], vw[k]) for k in vw)
+    c.close()
+
+
 def test_self_play_statistics_through_native_comm(tmp_path):
     import os
     from bokego_amd import selfplay

@@ -113,7 +113,12 @@ def _gloo_worker(rank, world, port, q):
     f = FakeNets()
     ev = selfplay.CallableEvaluator(f.policy, f.value)
     local, total = selfplay.self_play(ev, rank=rank, world=world, **KW)
-    q.put((rank, total, {k: v["moves"] for k, v in local["games"].items()}))
+    # generation start of the NEXT generation: rank 0's weights reach every rank (the other ranks hold junk)
+    g = np.random.default_rng(rank)
+    psd = {"conv.0.weight": g.standard_normal((4, 3, 5, 5)).astype(np.float32), "conv.0.bias": g.standard_normal(4).astype(np.float32)}
+    vsd = {"lin2.weight": g.standard_normal((1, 64)).astype(np.float32), "bn.num_batches_tracked": np.int64(3)}
+    bp, bv = selfplay.broadcast_weights(psd, vsd, src=0)
+    q.put((rank, total, {k: v["moves"] for k, v in local["games"].items()}, bp, bv))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,6 +144,13 @@ def test_end_of_generation_allreduce_world2_gloo():
     for r in res:
         merged.update(r[2])
     assert merged == {k: v["moves"] for k, v in g1.items()}
+    # broadcast_weights: both ranks now hold rank 0's tensors, names / shapes / order kept, BN counters dropped
+    g0 = np.random.default_rng(0)
+    want_p = {"conv.0.weight": g0.standard_normal((4, 3, 5, 5)).astype(np.float32), "conv.0.bias": g0.standard_normal(4).astype(np.float32)}
+    want_v = g0.standard_normal((1, 64)).astype(np.float32)
+    for r in res:
+        assert list(r[3]) == ["conv.0.weight", "conv.0.bias"] and list(r[4]) == ["lin2.weight"]
+        assert all(np.array_equal(r[3][k], want_p[k]) for k in want_p) and np.array_equal(r[4]["lin2.weight"], want_v)
 
 
 def test_pool_respects_cap_and_counts():
