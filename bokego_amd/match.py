@@ -7,6 +7,7 @@ A referee board (bokego_amd.go) validates every move and scores the final positi
 
     python -m bokego_amd.match --games 20 -r 400 --opponent policy
     python -m bokego_amd.match --games 100 -r 1600 --opponent "gnugo --mode gtp --chinese-rules"
+    python -m bokego_amd.match --games 100 -r 1600 --opening-plies 4 --opponent "python -m oracle.gtp_cpu -r 1600"   # CPU-backend baseline
 """
 import argparse
 import json
@@ -106,13 +107,33 @@ class PolicyEngine:
         pass
 
 
-def play_game(black, white, komi=5.5, max_moves=162):
+def random_opening(plies, seed):
+    """`plies` uniformly random legal, non-eye-filling moves from the empty board (seeded): two deterministic engines
+    would otherwise repeat the same game; a colour-swapped pair of games shares its opening."""
+    import ctypes
+    rng = np.random.default_rng(seed)
+    g = go.Game(moves=[])
+    for _ in range(plies):
+        color = 1 if g.turn % 2 == 0 else 2
+        ok = [m for m in g.get_legal_moves() if not go.golib().bk_pos_eye_like(ctypes.byref(g._pos), m, color)]
+        if not ok:
+            break
+        g.play_move(int(ok[int(rng.integers(0, len(ok)))]))
+    return list(g.moves)
+
+
+def play_game(black, white, komi=5.5, max_moves=162, opening=()):
     """One game; returns dict(result=+1 black / -1 white, score, moves, seconds per colour)."""
     ref = go.Game(moves=[], komi=komi)
     for e in (black, white):
         e.send("boardsize 9")
         e.send("clear_board")
         e.send(f"komi {komi}")
+    for mv in opening:
+        col = "bw"[ref.turn % 2]
+        ref.play_move(mv)
+        for e in (black, white):
+            e.send(f"play {col} {go.unsquash(mv)}")
     secs, n = [0.0, 0.0], [0, 0]
     passes, resigned = 0, None
     while passes < 2 and ref.turn < max_moves:
@@ -136,12 +157,13 @@ def play_game(black, white, komi=5.5, max_moves=162):
             "ms_per_move": [1e3 * secs[i] / max(1, n[i]) for i in (0, 1)]}
 
 
-def play_match(a, b, n_games=10, komi=5.5, out_sgf=None):
+def play_match(a, b, n_games=10, komi=5.5, out_sgf=None, opening_plies=0, seed=0):
     """a and b alternate colours; returns win counts and mean ms/move of each."""
     wins, ms, games = [0, 0], [[], []], []
     for gidx in range(n_games):
         a_black = gidx % 2 == 0
-        g = play_game(a, b, komi) if a_black else play_game(b, a, komi)
+        op = random_opening(opening_plies, seed + gidx // 2) if opening_plies else ()
+        g = play_game(a, b, komi, opening=op) if a_black else play_game(b, a, komi, opening=op)
         a_won = (g["result"] == 1) == a_black
         wins[0 if a_won else 1] += 1
         ms[0].append(g["ms_per_move"][0 if a_black else 1])
@@ -165,18 +187,22 @@ def main(argv=None):
     ap.add_argument("--opponent", default="policy", help='"policy" (raw policy, no search) or a GTP command line')
     ap.add_argument("--komi", type=float, default=5.5)
     ap.add_argument("--sgf", default=None, help="prefix for SGF records")
+    ap.add_argument("--opening-plies", type=int, default=0, help="seeded random opening moves per game pair (variety between deterministic engines)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default=None)
     args = ap.parse_args(argv)
     from . import nnet
     from .gtp import NativeGTP, load_state_dict
     from .mcts_native import Position
-    pi, val = nnet.HipPolicyNet(load_state_dict(args.p)), nnet.HipValueNet(load_state_dict(args.v))
+    pi = nnet.HipPolicyNet(load_state_dict(args.p), precision=args.precision)
+    val = nnet.HipValueNet(load_state_dict(args.v), precision=args.precision)
     a = InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=args.r),
                         name=f"boke-hip-r{args.r}")
     if args.opponent == "policy":
         b = PolicyEngine(pi)
     else:
         b = SubprocessEngine(args.opponent)
-    res = play_match(a, b, args.games, args.komi, args.sgf)
+    res = play_match(a, b, args.games, args.komi, args.sgf, args.opening_plies, args.seed)
     res.pop("records")
     print(json.dumps(res))
     a.close()

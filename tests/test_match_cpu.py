@@ -55,3 +55,25 @@ def test_subprocess_engine_speaks_gtp(tmp_path):
     # like the reference, the engine treats a position whose last move was a pass as over and passes back
     assert len(g["moves"]) == 3 and g["moves"][1:] == [go.PASS, go.PASS] and g["result"] == 1
     b.close()
+
+
+def test_random_openings_and_cpu_backend_engine_as_subprocess():
+    """Seeded openings give two deterministic engines different games (a colour-swapped pair shares its opening), and
+    the CPU-backend GTP engine (oracle/gtp_cpu.py: the same search on the reference's torch-CPU arithmetic, BASELINE
+    configs[4]'s "CPU baseline") plays a legal game through the subprocess protocol."""
+    assert match.random_opening(4, 7) == match.random_opening(4, 7) != match.random_opening(4, 8)
+    f = FakeNets()
+    a = match.InProcessEngine(_gtp(f, 20), name="mcts20")
+    env_cmd = f"{sys.executable} -m oracle.gtp_cpu -r 30 --threads 2"
+    cwd = os.getcwd()
+    os.chdir(REPO)
+    try:
+        b = match.SubprocessEngine(env_cmd, name="boke-cpu")
+        res = match.play_match(a, b, n_games=2, opening_plies=4, seed=3)
+        b.close()
+    finally:
+        os.chdir(cwd)
+    assert res["games"] == 2 and res["mcts20_wins"] + res["boke-cpu_wins"] == 2
+    op = match.random_opening(4, 3)
+    assert all(rec["moves"][:4] == op for rec in res["records"])
+    assert res["ms_per_move"]["boke-cpu"] > 0
