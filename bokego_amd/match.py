@@ -11,6 +11,7 @@ A referee board (bokego_amd.go) validates every move and scores the final positi
 """
 import argparse
 import json
+import os
 import shlex
 import subprocess
 import time
@@ -37,22 +38,50 @@ class InProcessEngine:
 
 
 class SubprocessEngine:
-    def __init__(self, command, name=None):
-        self.name = name or command.split()[0]
-        self.p = subprocess.Popen(shlex.split(command), stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+    """A GTP engine behind a pipe.  An engine that leaves its loop when a game ends -- the reference's does (a resignation
+    or `quit` clears `running`, gtp.py:110-118), and so does `python -m bokego_amd.gtp` -- is started again for the
+    next game: a command that finds the pipe closed is re-sent once to a fresh process."""
 
-    def send(self, cmd):
+    def __init__(self, command, name=None):
+        self.command = command
+        self.name = name or command.split()[0]
+        self.restarts = 0
+        self._spawn()
+
+    def _spawn(self):
+        self.p = subprocess.Popen(shlex.split(self.command), stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+    def _exchange(self, cmd):
         self.p.stdin.write(cmd + "\n")
         self.p.stdin.flush()
         lines = []
         while True:
             line = self.p.stdout.readline()
             if line == "":
-                raise RuntimeError(f"{self.name}: engine closed the pipe during '{cmd}'")
+                return None                       # the engine closed the pipe
             if line.strip() == "" and lines:
                 break
             if line.strip():
                 lines.append(line.rstrip("\n"))
+        return lines
+
+    def send(self, cmd):
+        try:
+            lines = self._exchange(cmd)
+        except BrokenPipeError:
+            lines = None
+        if lines is None:
+            try:
+                self.p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                self.p.kill()
+            if cmd.split()[0] == "quit":
+                return ""
+            self.restarts += 1
+            self._spawn()
+            lines = self._exchange(cmd)
+            if lines is None:
+                raise RuntimeError(f"{self.name}: engine closed the pipe during '{cmd}'")
         if not lines[0].startswith("="):
             raise RuntimeError(f"{self.name}: '{cmd}' -> {lines}")
         return "\n".join(lines)[1:].strip()
@@ -62,7 +91,10 @@ class SubprocessEngine:
             self.send("quit")
         except Exception:
             pass
-        self.p.wait(timeout=10)
+        try:
+            self.p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            self.p.kill()
 
 
 class PolicyEngine:
@@ -170,6 +202,7 @@ def play_match(a, b, n_games=10, komi=5.5, out_sgf=None, opening_plies=0, seed=0
         ms[1].append(g["ms_per_move"][1 if a_black else 0])
         games.append({"a_black": a_black, **g})
         if out_sgf:
+            os.makedirs(os.path.dirname(os.path.abspath(out_sgf)), exist_ok=True)
             go.write_sgf(g["moves"], f"{out_sgf}_{gidx + 1}.sgf", komi=komi, B=a.name if a_black else b.name,
                          W=b.name if a_black else a.name, result=("B+" if g["score"] > 0 else "W+") + f"{abs(g['score'])}")
     return {"games": n_games, a.name + "_wins": wins[0], b.name + "_wins": wins[1], "win_rate": wins[0] / n_games,
