@@ -379,16 +379,19 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
     };
     f32x4 A0[8], A1[8], W0[4], W1[4], W2[4], W3[4];     // activations: ping-pong per group; weights: ring, 2 groups ahead
 
-    // one group of 16 input slots with ring slots (Wc: this group's weights, Wn: receives the group two ahead)
-    auto do_group = [&](auto LOc, auto HIc, auto GIc, f32x4 (&Wc)[4], f32x4 (&Wn)[4], int delta) {
-        constexpr int lo = decltype(LOc)::value, hi = decltype(HIc)::value, g = decltype(GIc)::value;
+    // one group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
+    // taps: the five interior tiles always run; the x-edge tile (0) and the two y-edge tiles (6, 7) sit behind
+    // wave-uniform branches (four specialised copies of the tap body -- 33 KB of straight-line MFMAs -- thrashed the
+    // instruction cache: 34.2 cycles per MFMA instead of 32)
+    auto do_group = [&](auto GIc, f32x4 (&Wc)[4], f32x4 (&Wn)[4], int delta, bool skip_x, bool skip_y) {
+        constexpr int g = decltype(GIc)::value;
         constexpr int JN = (FIRST && g == 1) ? 3 : 4;   // layer 0: planes 16..26 take 3 k-steps
         f32x4 (&Ac)[8] = (g & 1) ? A1 : A0;
         f32x4 (&An)[8] = (g & 1) ? A0 : A1;
         load_w(Wn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = lo; rt < hi; ++rt)
+        for (int rt = 1; rt < 6; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][0], Ac[rt][0], acc[rt][ct], 0, 0, 0);
@@ -403,10 +406,29 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
 #pragma unroll
         for (int j = 1; j < JN; ++j)
 #pragma unroll
-            for (int rt = lo; rt < hi; ++rt)
+            for (int rt = 1; rt < 6; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip_x) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[0][j], acc[0][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip_y) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int rt = 6; rt < 8; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -416,37 +438,29 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
     using I5 = std::integral_constant<int, 5>;
     using I6 = std::integral_constant<int, 6>;
     using I7 = std::integral_constant<int, 7>;
-    using I8 = std::integral_constant<int, 8>;
-    // one tap with the tile range [LO, HI); PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
-    auto do_tap = [&](auto LOc, auto HIc, auto PHc, int delta) {
-        if constexpr (FIRST) {
-            if constexpr (decltype(PHc)::value == 0) {
-                do_group(LOc, HIc, I0{}, W0, W2, delta);
-                do_group(LOc, HIc, I1{}, W1, W3, delta);
-            } else {
-                do_group(LOc, HIc, I0{}, W2, W0, delta);
-                do_group(LOc, HIc, I1{}, W3, W1, delta);
-            }
-        } else {
-            do_group(LOc, HIc, I0{}, W0, W2, delta);
-            do_group(LOc, HIc, I1{}, W1, W3, delta);
-            do_group(LOc, HIc, I2{}, W2, W0, delta);
-            do_group(LOc, HIc, I3{}, W3, W1, delta);
-            do_group(LOc, HIc, I4{}, W0, W2, delta);
-            do_group(LOc, HIc, I5{}, W1, W3, delta);
-            do_group(LOc, HIc, I6{}, W2, W0, delta);
-            do_group(LOc, HIc, I7{}, W3, W1, delta);
-        }
-    };
+    // one tap; PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
     auto tap = [&](auto PHc, int t) {
         const int ky = t / KW, kx = t - ky * KW;
         const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
-        const bool skip_x = wm == 0 ? kx < KW / 2 : kx > KW / 2;   // this wave's x-edge tile reads only zero halo
-        const bool skip_y = wm == 0 ? ky < KW / 2 : ky > KW / 2;   // ... its two y-edge tiles do
-        if (skip_x) {
-            if (skip_y) do_tap(I1{}, I6{}, PHc, d); else do_tap(I1{}, I8{}, PHc, d);
+        const bool sx = wm == 0 ? kx < KW / 2 : kx > KW / 2;   // this wave's x-edge tile reads only zero halo
+        const bool sy = wm == 0 ? ky < KW / 2 : ky > KW / 2;   // ... its two y-edge tiles do
+        if constexpr (FIRST) {
+            if constexpr (decltype(PHc)::value == 0) {
+                do_group(I0{}, W0, W2, d, sx, sy);
+                do_group(I1{}, W1, W3, d, sx, sy);
+            } else {
+                do_group(I0{}, W2, W0, d, sx, sy);
+                do_group(I1{}, W3, W1, d, sx, sy);
+            }
         } else {
-            if (skip_y) do_tap(I0{}, I6{}, PHc, d); else do_tap(I0{}, I8{}, PHc, d);
+            do_group(I0{}, W0, W2, d, sx, sy);
+            do_group(I1{}, W1, W3, d, sx, sy);
+            do_group(I2{}, W2, W0, d, sx, sy);
+            do_group(I3{}, W3, W1, d, sx, sy);
+            do_group(I4{}, W0, W2, d, sx, sy);
+            do_group(I5{}, W1, W3, d, sx, sy);
+            do_group(I6{}, W2, W0, d, sx, sy);
+            do_group(I7{}, W3, W1, d, sx, sy);
         }
     };
 
