@@ -328,8 +328,12 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     gids = shard_game_ids(n_games, rank, world)
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits)
-    if n_pools is None:   # measured: three rotating pools pay off from ~200 games per rank, two below
-        n_pools = 3 if len(gids) >= 192 else 2
+    if n_pools is None:
+        # measured (512 games on one MI355X): with the f16x2 kernel the host is nearly the limit and three rotating pools
+        # pay off from ~200 games per rank; with the fp32 kernel the GPU is 3.6x slower per batch, the host has slack,
+        # and two larger pools win (7,930 vs 7,857 games/min: fuller batches, less round quantisation)
+        fp32 = getattr(getattr(evaluator, "engine", None), "precision", "f16x2") == "f32"
+        n_pools = 3 if (len(gids) >= 192 and not fp32) else 2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     parts = [gids[i::n_pools] for i in range(n_pools)]
     pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
