@@ -498,15 +498,22 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     if (B > 0) {
         std::memcpy(s->h_in, src, bytes);
         HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, sin));
-        if (src_kind == kSrcPositions) {
-            // chained: the encoder runs on the copy-in stream, small workgroups (3 KB LDS) that fit beside the
-            // 3-board leaf workgroups of the previous request still running on the compute stream
+        // The encoder (13 us per 4,096 records) runs on the COMPUTE stream, in front of the request's leaf kernel.  Round 1
+        // launched it on the copy-in stream so that it overlapped the previous request's leaf kernel; under that
+        // kernel its workgroups wait for CUs, so it "ran" 110-370 us per call (6-8 % of the summed kernel time of a
+        // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  BK_ENCODE_OVERLAP=1 restores that.
+        static const bool enc_overlap = getenv("BK_ENCODE_OVERLAP") != nullptr;
+        if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
             HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             e->st.positions_encoded += (uint64_t)B;
         }
         if (chained) {
             HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
             HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
+        }
+        if (src_kind == kSrcPositions && !enc_overlap && chained) {
+            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->stream));
+            e->st.positions_encoded += (uint64_t)B;
         }
         // output block of this request
         s->off_values = 64;

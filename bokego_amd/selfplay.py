@@ -453,6 +453,8 @@ def main():
     ap.add_argument("--pools", type=int, default=None, help="lock-step pools per rank (host/GPU overlap; default 3 from 192 games per rank, else 2)")
     ap.add_argument("--host-encode", action="store_true", help="encode the 27 planes on the host instead of on the GPU")
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
+                    help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     args = ap.parse_args()
 
     import torch
@@ -475,7 +477,7 @@ def main():
         return ck.get("model_state_dict", ck)
 
     eng = LeafEngine(load(args.policy, "policy_19.bkw"), load(args.value, "value_synth.bkw"), device_id=local_rank,
-                     max_batch=args.max_batch)
+                     max_batch=args.max_batch, precision=args.precision)
     ev = EngineEvaluator(eng, gpu_encode=not args.host_encode)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
