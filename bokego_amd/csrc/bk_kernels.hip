@@ -130,10 +130,16 @@ struct RowMap {
 //                no vector address arithmetic, no 64-bit pointer carries;
 //   both software-pipelined through register ping-pong (A one group ahead, B one block ahead).
 // rowa[mt]: byte offset of this lane's row of tile mt at tap (0,0), chunk h (RowAddr below; computed once per kernel).
-template <int NB, bool FIRST>
+// B0 / B1: the weight ping-pong buffers, owned by the kernel so that they live across layers: the loop's last block
+// always fetches "the next block", which is the first block of the NEXT layer (the layers are contiguous in memory).
+// PRELOADED: B0 already holds this layer's block 0 (fetched by the previous layer's last step, or ahead of the input
+// staging for layer 0), so the layer starts without waiting for an L2 round trip.  On return B1 (layer 0: 25 blocks)
+// resp. B0 (3x3 layers: 36 blocks) holds the next layer's block 0.
+template <int NB, bool FIRST, bool PRELOADED>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
                                            f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn,
-                                           const int (&rowa)[Geo<NB>::MTW]) {
+                                           const int (&rowa)[Geo<NB>::MTW], f32x4 (&B0)[4][Geo<NB>::NT],
+                                           f32x4 (&B1)[4][Geo<NB>::NT]) {
     using G = Geo<NB>;
     constexpr int MTW = G::MTW, NT = G::NT;
     constexpr int KW = FIRST ? 5 : 3;
@@ -154,7 +160,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     // reads cout tiles wn*NT .. wn*NT+NT-1: NT coalesced 1 KiB loads per group.
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + (wn * NT) * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
-    int boff = 0;                                       // scalar: byte offset of the block being fetched
+    int boff = PRELOADED ? 16384 : 0;                   // scalar: byte offset of the block being fetched
     auto load_b = [&](f32x4 (&B)[4][NT]) {
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
@@ -168,7 +174,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         for (int mt = 0; mt < MTW; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + imm);
     };
 
-    f32x4 A0[MTW], A1[MTW], B0[4][NT], B1[4][NT];
+    f32x4 A0[MTW], A1[MTW];
 
     // One block = 4 groups.  Bc: its fragments, Bn receives the next block's.  Group parity alternates A0/A1.
     // GB: the block's index inside its tap (compile time).  At the tap's last group the tap pointers move on
@@ -242,7 +248,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         }
     };
 
-    load_b(B0);
+    if constexpr (!PRELOADED) load_b(B0);
     read_a(A0, 0);
     if constexpr (NB == 3 && !FIRST) {
         // ky=0 is taps [0,3), ky=2 taps [6,9)
@@ -359,6 +365,17 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
     STAMP(0);
+    // weight ping-pong buffers (see conv_layer); layer 0's first block is requested before the input staging
+    const int wm = wave / G::WN, wn = wave - wm * G::WN;
+    f32x4 Bw0[4][G::NT], Bw1[4][G::NT];
+    {
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + (wn * G::NT) * 256), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int nt = 0; nt < G::NT; ++nt)
+                Bw0[gg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + nt * 1024, gg * 4096, 0));
+    }
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
     // every thread fetches its <= ceil(NB*2187/256) elements first (all loads in flight: the loop used to pay one
     // global-memory latency per element), then scatters them; non-temporal: the planes are read once and must not
@@ -398,7 +415,6 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
 
     STAMP(1);
     f32x16 acc[G::MTW][G::NT];
-    const int wm = wave / G::WN, wn = wave - wm * G::WN;
     // this lane's GEMM rows, decoded ONCE (the decode has divisions): LDS byte offsets for the A-fragment reads of
     // layer 0 / layers 1..6 (tap (0,0), chunk h) and for the epilogue stores (record + this wave's cout block)
     int rowa0[G::MTW], rowa3[G::MTW], storea[G::MTW];
@@ -414,11 +430,21 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
     load_bias<NB>(bv, P.bias, wn, h);
 
     // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer<NB, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0);
+    conv_layer<NB, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Bw0, Bw1);   // leaves layer 1's block 0 in Bw1
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
-    // the 128-ch layout overlaps the input region: clear it all (halo must be zero)
-    for (int i = tid; i < G::L3_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the 128-ch layout overlaps the input region: the halo must read as zero
+    if constexpr (NB == 3) {
+        // every data record is about to be overwritten in full (27 rows x 9 points x 128 channels): clear only the 38
+        // halo records -- row 0, column 0 of rows 1..27, and the record behind the last row (20 KB instead of 147 KB)
+        for (int i = tid; i < 38 * (REC3 / 16); i += 256) {
+            const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
+            const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
+            *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        for (int i = tid; i < G::L3_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     STAMP(3);
     store_layer<NB>(actb, acc, bv, storea);
@@ -430,7 +456,7 @@ __global__ void __launch_bounds__(256) bk_leaf_eval_kernel(const bk_eval_args a)
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
         load_bias<NB>(bv, P.bias + L * 128, wn, h);
-        conv_layer<NB, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3);
+        conv_layer<NB, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Bw1, Bw0);   // roles swapped: in Bw1, out Bw1
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
