@@ -111,16 +111,19 @@ __global__ void __launch_bounds__(256) bk_encode_kernel(const unsigned char* __r
     {
         const BB own = me_board == 1 ? black : white;
         bool changed = live && me_board != 0;
-        while (__any(changed)) {           // wave-uniform: at most 81 rounds, normally a handful
-            const BB nx = (x | dilate(x)) & own;
+        BB d = dilate(x);                  // kept in step with x: after the loop it is the chain's neighbourhood
+        for (;;) {                         // wave-uniform exit: at most 81 rounds, normally a handful
+            const BB nx = (x | d) & own;
             changed = changed && (nx != x);
+            if (!__any(changed)) break;
             if (changed) x = nx;
+            d = dilate(x);
 #if BK_ENC_EXP == 2
             break;
 #endif
         }
         if (live && me_board != 0) {
-            const BB lib = dilate(x) & empty;
+            const BB lib = d & empty;
             unsigned only = 255u;
             if (popc(lib) == 1)
                 only = lib.w[0] ? __ffs(lib.w[0]) - 1 : lib.w[1] ? 27 + __ffs(lib.w[1]) - 1 : 54 + __ffs(lib.w[2]) - 1;
