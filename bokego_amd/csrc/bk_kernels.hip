@@ -10,13 +10,14 @@
 //     one and the left halo of the next), so every 3x3 tap is a constant address offset and
 //     needs no bounds test; records are padded (528 B per position) so that the 16 lanes of a
 //     ds_read_b128 group hit 16 distinct LDS slots without any address swizzling;
-//   * each conv layer is an implicit GEMM  [32*MT rows] x [128 couts] x [taps*cin]  on the
-//     exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32; wave w owns couts 32w..32w+31 for
-//     ALL rows, so every weight is fetched by exactly one wave, straight from L2 into
-//     registers, in a host-prepacked fragment order (one coalesced 1 KiB read per 8 cin);
+//   * each conv layer is an implicit GEMM  [32*MT positions] x [128 couts] x [taps*cin]  on the
+//     exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32, computed transposed (weights = A operand);
+//     the 4 waves form a 2x2 grid over [position tiles x cout tiles] (1x4 for NB = 1), every weight
+//     fragment comes straight from L2 into registers in a host-prepacked order (coalesced 1 KiB buffer
+//     loads, scalar offsets), and the conv loops contain no vector-ALU instruction besides the MFMAs;
 //   * the layer output stays in the accumulators until every wave has finished reading the
-//     layer input, then is written back IN PLACE (bias + ReLU fused): no ping-pong buffer,
-//     which is what lets 3 boards (159 KB) fit the 160 KB LDS;
+//     layer input, then is written back IN PLACE (bias + ReLU fused, 16-byte stores): no ping-pong
+//     buffer, which is what lets 3 boards (147 KB) fit the 160 KB LDS;
 //   * the untied-bias 1x1 head, the 81-way softmax and the value MLP + tanh are wave-level
 //     reductions at the end of the same kernel.
 // HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2
