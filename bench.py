@@ -108,7 +108,8 @@ def cpu_baseline(pw, vw, x, budget_s=20.0):
 
     visible, quota, physical = usable_cores()
     # a 1-GPU box gets a 16-CPU share of the host: more threads than that only fight over it
-    cores = int(os.environ.get("BK_CPU_THREADS", min(physical, quota or physical, 16 if quota is None and visible > 64 else physical)))
+    cores = min(physical, quota) if quota else (16 if visible > 64 else physical)
+    cores = int(os.environ.get("BK_CPU_THREADS", cores))
     P, V = TorchPolicy(pw), TorchValue(vw)
     xt = torch.from_numpy(x)
     old = torch.get_num_threads()

@@ -77,6 +77,9 @@ class SubprocessEngine:
                 self.p.kill()
             if cmd.split()[0] == "quit":
                 return ""
+            # a fresh process has an empty board: only the commands that open a game may be replayed to it
+            if cmd.split()[0] not in ("boardsize", "clear_board", "name", "version", "protocol_version"):
+                raise RuntimeError(f"{self.name}: engine died during '{cmd}' (exit code {self.p.poll()})")
             self.restarts += 1
             self._spawn()
             lines = self._exchange(cmd)
