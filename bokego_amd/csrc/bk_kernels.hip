@@ -93,9 +93,12 @@ struct Geo {
 #ifndef BK_FP32_NW3
 #define BK_FP32_NW3 8
 #endif
-    static constexpr int NW = NB == 1 ? 4 : NB == 2 ? BK_FP32_NW2 : BK_FP32_NW3;
+#ifndef BK_FP32_NW1
+#define BK_FP32_NW1 4
+#endif
+    static constexpr int NW = NB == 1 ? BK_FP32_NW1 : NB == 2 ? BK_FP32_NW2 : BK_FP32_NW3;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int WM = (MT % 2 == 0) ? 2 : 1;
+    static constexpr int WM = NW == 12 ? 3 : (MT % 2 == 0) ? 2 : 1;   // 12 waves: the 1-board form, one wave per (position tile, cout tile)
     static constexpr int WN = NW / WM;
     static constexpr int NT = 4 / WN;
     static constexpr int MTW = MT / WM;
