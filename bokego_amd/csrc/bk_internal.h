@@ -9,7 +9,7 @@
 #define BK_L0_FLOATS (25 * 4 * 1024)
 #define BK_L3_FLOATS (9 * 16 * 1024)
 #define BK_WFRAG_FLOATS (BK_L0_FLOATS + 6 * BK_L3_FLOATS)
-#define BK_WFRAG_PAD_FLOATS 4096  // the B prefetch reads one block (4 groups, 16 KiB) past the last layer
+#define BK_WFRAG_PAD_FLOATS 8192  // the weight prefetch runs up to 32 KiB past the last layer (fine path: 3 groups of 8 KiB)
 
 // f16x2 path: per layer [k16 step][cout tile (4)][piece hi/lo][lane (64)][8 halfs] = 4096 halfs per step
 #define BK16_L0_STEPS 52                      // 25 taps x 2 steps, zero-padded to a multiple of 4
@@ -27,6 +27,10 @@
 struct bk_net_params {
     const float* wfrag;    // BK_WFRAG_FLOATS (+pad), BatchNorm folded
     const float* bias;     // [7][128] folded conv bias
+    // fine-tile fp32 path (16x16x4 MFMA, 3-board workgroups): same sizes, other fragment order, channels of layers
+    // 0..5 kept in a permuted slot order (bk_fine_perm) that reproduces the coarse path's summation order bit for bit
+    const float* wfragF;
+    const float* biasF;    // [7][128] folded bias in slot order
     const float* head_w;   // [128]  (value net: BatchNorm2d(1) folded in)
     const float* head_b;   // [81]
     const float* lin1_wt;  // value: [81][64] = lin1.weight^T with BatchNorm1d folded
@@ -60,6 +64,10 @@ struct bk_eval_args {
     int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
+
+// fine path: real channel held by slot s of a layer-0..5 output record (a bit permutation inside each block of 16):
+// slot = 16g + 4kq + j is what MFMA k-step j of channel group g consumes from lane quad kq
+static inline int bk_fine_perm(int s) { return (s & ~15) | (((s >> 1) & 1) << 3) | (((s >> 2) & 1) << 2) | ((s & 1) << 1) | ((s >> 3) & 1); }
 
 #define BK_POS_BYTES 192  // sizeof(bk_pos), include/bokego_go.h
 

@@ -337,6 +337,196 @@ __device__ __forceinline__ void store_layer(char* actb, const f32x16 (&acc)[Geo<
     }
 }
 
+// ================================ fine-tile path (3-board workgroups) ================================================
+// Same workgroup (8 waves: 2 position groups x 4 cout groups), same LDS layout, same arithmetic -- but 16-row tiles (v_mfma_f32_16x16x4_f32: 16 positions x 16 couts
+// x 4 input channels, 32 cycles, the same FLOP rate as the 32x32x2 form).  With 16 tiles instead of 8 the 243 board
+// points can be grouped by edge class, so more all-zero-halo taps are skipped: per wave (wm = 0 / 1) the 8 tiles are
+//     [ x-edge | 5 interior | y-edge a | y-edge b ]     x-edge: 16 points with x = 0 (wm 0) / x = 8 (wm 1), y in 1..7
+//                                                        y-edge: the 27 points with y = 0 / y = 8 (+ 5 padding rows)
+//                                                        interior: the rest (+ 3 padding rows at the very end)
+// and a tap skips the x-edge tile when dx points off the board for it, the two y-edge tiles when dy does: the active
+// tiles are always a contiguous range [LO, HI), LO in {0,1}, HI in {6,8}.  3x3 layers: 63 of 72 tile-taps (coarse
+// path: 66 of 72 in 32-row units), layer 0: 170 of 200 (coarse: 180): 4.6 % fewer MFMA cycles.
+// Channels: an MFMA k-step consumes 4 input channels, one per lane quad kq, and a lane's accumulator holds 4
+// consecutive output slots.  Outputs of layers 0..5 are kept in the slot order bk_fine_perm (bk_internal.h), which makes
+// the k order of every dot product equal to the coarse path's (8-channel groups, pairs (j, j+4)): the two paths agree
+// BIT FOR BIT.  Layer 6 writes natural channel order for the heads.  The host packs weights and biases accordingly.
+struct FineRow { int b, y, x; bool valid; };
+__device__ __forceinline__ FineRow fine_row(int wm, int rt, int p16) {
+    FineRow r{0, 4, 0, true};
+    if (rt == 0) {                       // x-edge tile: the first 16 of the 21 points (b, y = 1..7, x = 0 or 8)
+        r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = wm ? 8 : 0;
+    } else if (rt <= 5) {                // interior pool: 147 interior points, then the 5 + 5 x-edge points left over
+        const int i = wm * 80 + (rt - 1) * 16 + p16;
+        if (i < 147) { r.b = i / 49; const int rem = i - 49 * r.b; r.y = 1 + rem / 7; r.x = 1 + rem % 7; }
+        else if (i < 157) { const int jx = 16 + (i - 147) % 5; r.b = jx / 7; r.y = 1 + jx % 7; r.x = i < 152 ? 0 : 8; }
+        else r.valid = false;
+    } else {                             // y-edge tiles: (b, y = 0 or 8, x = 0..8)
+        const int i = (rt - 6) * 16 + p16;
+        if (i < 27) { r.b = i / 9; r.x = i % 9; r.y = wm ? 8 : 0; }
+        else r.valid = false;
+    }
+    if (!r.valid) { r.b = 0; r.y = 4; r.x = 0; }   // padding rows compute from a valid address; stored to the dummy record
+    return r;
+}
+// float slot of input plane c inside a layer-0 record: planes 0..23 by the inverse of bk_fine_perm, planes 24..26 are
+// k-step 2 of the second channel group (slot 16 + 4kq + 2 for lane quad kq = c - 24)
+__device__ __forceinline__ int in_slot_fine(int c) {
+    return c < 24 ? (c & ~15) | ((c & 1) << 3) | (c & 4) | (((c >> 3) & 1) << 1) | ((c >> 1) & 1) : 16 + 4 * (c - 24) + 2;
+}
+
+// wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk_fine).
+// rowa[rt]: byte offset of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4).
+template <bool FIRST>
+__device__ __forceinline__ void conv_layer_fine(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[8][2],
+                                                int lane, int wm, int wn, const int (&rowa)[8]) {
+    constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
+    constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
+    constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
+    const char* ap[8];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) ap[rt] = actb + rowa[rt];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's 2 cout tiles (2*wn, 2*wn+1 of 8): 1 KiB per tile and group, 8 KiB per group
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + wn * 2 * 256), 0, 0x7ffffff0, 0x00020000);
+    const int lane16 = lane * 16;
+    int boff = 0;                                       // scalar: byte offset of the group being fetched
+    auto load_w = [&](f32x4 (&W)[2]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            W[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16 + ct * 1024, boff, 0));
+        boff += 8192;
+    };
+    auto read_a = [&](f32x4 (&A)[8], int imm) {
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
+    };
+    f32x4 A0[8], A1[8], W0[2], W1[2], W2[2], W3[2];     // activations: ping-pong per group; weights: ring, 2 groups ahead
+
+    // one group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
+    // taps: the five interior tiles always run; the x-edge tile (0) and the two y-edge tiles (6, 7) sit behind
+    // wave-uniform branches (four specialised copies of the tap body -- 33 KB of straight-line MFMAs -- thrashed the
+    // instruction cache: 34.2 cycles per MFMA instead of 32)
+    auto do_group = [&](auto GIc, f32x4 (&Wc)[2], f32x4 (&Wn)[2], int delta, bool skip_x, bool skip_y) {
+        constexpr int g = decltype(GIc)::value;
+        constexpr int JN = (FIRST && g == 1) ? 3 : 4;   // layer 0: planes 16..26 take 3 k-steps
+        f32x4 (&Ac)[8] = (g & 1) ? A1 : A0;
+        f32x4 (&An)[8] = (g & 1) ? A0 : A1;
+        load_w(Wn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 1; rt < 6; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][0], Ac[rt][0], acc[rt][ct], 0, 0, 0);
+        if (g == G - 1) {                               // next group is group 0 of the next tap
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) ap[rt] += delta;
+            read_a(An, 0);
+        } else {
+            read_a(An, (g + 1) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < JN; ++j)
+#pragma unroll
+            for (int rt = 1; rt < 6; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip_x) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[0][j], acc[0][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip_y) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int rt = 6; rt < 8; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    using I7 = std::integral_constant<int, 7>;
+    // one tap; PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
+    auto tap = [&](auto PHc, int t) {
+        const int ky = t / KW, kx = t - ky * KW;
+        const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
+        const bool sx = wm == 0 ? kx < KW / 2 : kx > KW / 2;   // this wave's x-edge tile reads only zero halo
+        const bool sy = wm == 0 ? ky < KW / 2 : ky > KW / 2;   // ... its two y-edge tiles do
+        if constexpr (FIRST) {
+            if constexpr (decltype(PHc)::value == 0) {
+                do_group(I0{}, W0, W2, d, sx, sy);
+                do_group(I1{}, W1, W3, d, sx, sy);
+            } else {
+                do_group(I0{}, W2, W0, d, sx, sy);
+                do_group(I1{}, W3, W1, d, sx, sy);
+            }
+        } else {
+            do_group(I0{}, W0, W2, d, sx, sy);
+            do_group(I1{}, W1, W3, d, sx, sy);
+            do_group(I2{}, W2, W0, d, sx, sy);
+            do_group(I3{}, W3, W1, d, sx, sy);
+            do_group(I4{}, W0, W2, d, sx, sy);
+            do_group(I5{}, W1, W3, d, sx, sy);
+            do_group(I6{}, W2, W0, d, sx, sy);
+            do_group(I7{}, W3, W1, d, sx, sy);
+        }
+    };
+
+    load_w(W0);
+    load_w(W1);
+    read_a(A0, 0);
+    if constexpr (FIRST) {
+#pragma unroll 1
+        for (int t = 0; t + 1 < TAPS; t += 2) {
+            tap(I0{}, t);
+            tap(I2{}, t + 1);
+        }
+        tap(I0{}, TAPS - 1);
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < TAPS; ++t) tap(I0{}, t);
+    }
+}
+
+// bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 32*wn + 16*ct + 4*kq .. +3 of its position
+__device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[8][2], const f32x4 (&bv)[2], const int (&storea)[8]) {
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        char* wp = actb + storea[rt];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][ct][e] + bv[ct][e], 0.f);
+            *reinterpret_cast<f32x4*>(wp + ct * 64) = v;
+        }
+    }
+}
+__device__ __forceinline__ void load_bias_fine(f32x4 (&bv)[2], const float* __restrict__ biasF, int wn, int kq) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(biasF + 32 * wn + 16 * ct + 4 * kq);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -351,8 +541,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // GATED: the redo of an f16x2 call on the device-pointer path (bk_eval_device*), enqueued right behind the f16x2
 // kernel on the same stream: a no-op unless that kernel raised the call's overflow tag.  A separate instantiation so
 // that profiles keep the real fp32 launches and these (normally empty) ones apart.
-template <int NB, bool GATED>
+// FINE: the 16-row-tile form of the conv layers (3-board workgroups only), see conv_layer_fine
+template <int NB, bool GATED, bool FINE>
 __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk_eval_args a) {
+    static_assert(!FINE || (NB == 3 && Geo<NB>::NW == 8 && Geo<NB>::WM == 2), "the fine-tile path is laid out for 8-wave 3-board workgroups");
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
@@ -391,7 +583,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // weight ping-pong buffers (see conv_layer); layer 0's first block is requested before the input staging
     const int wm = wave / G::WN, wn = wave - wm * G::WN;
     f32x4 Bw0[4][G::NT], Bw1[4][G::NT];
-    {
+    if constexpr (!FINE) {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + (wn * G::NT) * 256), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
@@ -430,13 +622,55 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
             const int e = tid + G::THREADS * k;
             if (e < n) {
                 const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
+                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + (FINE ? in_slot_fine(c) : in_slot(c)) * 4) = v[k];
             }
         }
     }
     __syncthreads();
 
     STAMP(1);
+    if constexpr (FINE) {
+        const int kq = lane >> 4;
+        f32x4 acc[8][2];
+        // this lane's 8 positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
+        // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's 32 couts)
+        int rowa0[8], rowa3[8], storea[8];
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            const FineRow fr = fine_row(wm, rt, lane & 15);
+            rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
+            rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
+            storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (32 * wn + 4 * kq) * 4 : dummy_byte;
+        }
+        f32x4 bv[2];
+        load_bias_fine(bv, P.biasF, wn, kq);
+        conv_layer_fine<true>(actb, P.wfragF, acc, lane, wm, wn, rowa0);
+        STAMP(2);
+        __syncthreads();  // everyone done reading the input planes
+        for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {   // clear the 38 halo records (see the coarse path)
+            const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
+            const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
+            *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        STAMP(3);
+        store_layer_fine(actb, acc, bv, storea);
+        STAMP(4);
+        __syncthreads();
+        STAMP(5);
+#pragma unroll 1
+        for (int L = 1; L < 7; ++L) {
+            load_bias_fine(bv, P.biasF + L * 128, wn, kq);
+            conv_layer_fine<false>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3);
+            STAMP(2 + 4 * L);
+            __syncthreads();
+            STAMP(3 + 4 * L);
+            store_layer_fine(actb, acc, bv, storea);
+            STAMP(4 + 4 * L);
+            __syncthreads();
+            STAMP(5 + 4 * L);
+        }
+    } else {
     f32x16 acc[G::MTW][G::NT];
     // this lane's GEMM rows, decoded ONCE (the decode has divisions): LDS byte offsets for the A-fragment reads of
     // layer 0 / layers 1..6 (tap (0,0), chunk h) and for the epilogue stores (record + this wave's cout block)
@@ -487,6 +721,8 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
+    }
+
     }
 
     // ---- heads: wave w handles board w ----
@@ -542,13 +778,13 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     STAMP(30);
 }
 
-template <int NB, bool GATED>
+template <int NB, bool GATED, bool FINE>
 hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
     static bool attr_set_dev[64] = {false};  // the attribute is per device: one flag per device ordinal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     bool& attr_set = attr_set_dev[dev];
-    auto kern = bk_leaf_eval_kernel<NB, GATED>;
+    auto kern = bk_leaf_eval_kernel<NB, GATED, FINE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NB>::LDS_BYTES);
@@ -593,16 +829,18 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
 }
 
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {
+    // 3-board workgroups run the fine-tile form; BK_FP32_COARSE=1 selects the 32-row-tile form (same bits) for A/B runs
+    static const bool fine = getenv("BK_FP32_COARSE") == nullptr;
     if (a.gate) {
         switch (nb) {
-            case 1: return launch_nb<1, true>(a, stream);
-            case 2: return launch_nb<2, true>(a, stream);
-            default: return launch_nb<3, true>(a, stream);
+            case 1: return launch_nb<1, true, false>(a, stream);
+            case 2: return launch_nb<2, true, false>(a, stream);
+            default: return fine ? launch_nb<3, true, true>(a, stream) : launch_nb<3, true, false>(a, stream);
         }
     }
     switch (nb) {
-        case 1: return launch_nb<1, false>(a, stream);
-        case 2: return launch_nb<2, false>(a, stream);
-        default: return launch_nb<3, false>(a, stream);
+        case 1: return launch_nb<1, false, false>(a, stream);
+        case 2: return launch_nb<2, false, false>(a, stream);
+        default: return fine ? launch_nb<3, false, true>(a, stream) : launch_nb<3, false, false>(a, stream);
     }
 }
