@@ -377,9 +377,14 @@ __device__ __forceinline__ int in_slot_fine(int c) {
 
 // wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk_fine).
 // rowa[rt]: byte offset of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4).
-template <bool FIRST>
+// W0..W3: the weight ring, owned by the kernel so that it lives across layers: the last two groups of a layer fetch
+// "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
+// PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
+// after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
+template <bool FIRST, bool PRELOADED>
 __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[8][2],
-                                                int lane, int wm, int wn, const int (&rowa)[8]) {
+                                                int lane, int wm, int wn, const int (&rowa)[8], f32x4 (&W0)[2],
+                                                f32x4 (&W1)[2], f32x4 (&W2)[2], f32x4 (&W3)[2]) {
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
     constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
@@ -394,7 +399,7 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
     // this wave's 2 cout tiles (2*wn, 2*wn+1 of 8): 1 KiB per tile and group, 8 KiB per group
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + wn * 2 * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
-    int boff = 0;                                       // scalar: byte offset of the group being fetched
+    int boff = PRELOADED ? 2 * 8192 : 0;                // scalar: byte offset of the group being fetched
     auto load_w = [&](f32x4 (&W)[2]) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -405,7 +410,7 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
     };
-    f32x4 A0[8], A1[8], W0[2], W1[2], W2[2], W3[2];     // activations: ping-pong per group; weights: ring, 2 groups ahead
+    f32x4 A0[8], A1[8];                                 // activations: ping-pong per group (weights: ring, 2 groups ahead)
 
     // one group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
     // taps: the five interior tiles always run; the x-edge tile (0) and the two y-edge tiles (6, 7) sit behind
@@ -492,8 +497,10 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         }
     };
 
-    load_w(W0);
-    load_w(W1);
+    if constexpr (!PRELOADED) {
+        load_w(W0);
+        load_w(W1);
+    }
     read_a(A0, 0);
     if constexpr (FIRST) {
 #pragma unroll 1
@@ -583,6 +590,15 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // weight ping-pong buffers (see conv_layer); layer 0's first block is requested before the input staging
     const int wm = wave / G::WN, wn = wave - wm * G::WN;
     f32x4 Bw0[4][G::NT], Bw1[4][G::NT];
+    f32x4 Wr0[2], Wr1[2], Wr2[2], Wr3[2];   // fine path: the weight ring (see conv_layer_fine)
+    if constexpr (FINE) {
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfragF + wn * 2 * 256), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            Wr0[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 0, 0));
+            Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
+        }
+    }
     if constexpr (!FINE) {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + (wn * G::NT) * 256), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
@@ -644,7 +660,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         }
         f32x4 bv[2];
         load_bias_fine(bv, P.biasF, wn, kq);
-        conv_layer_fine<true>(actb, P.wfragF, acc, lane, wm, wn, rowa0);
+        conv_layer_fine<true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
         STAMP(2);
         __syncthreads();  // everyone done reading the input planes
         for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {   // clear the 38 halo records (see the coarse path)
@@ -661,7 +677,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 #pragma unroll 1
         for (int L = 1; L < 7; ++L) {
             load_bias_fine(bv, P.biasF + L * 128, wn, kq);
-            conv_layer_fine<false>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3);
+            conv_layer_fine<false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
             STAMP(2 + 4 * L);
             __syncthreads();
             STAMP(3 + 4 * L);
