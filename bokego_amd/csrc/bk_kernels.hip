@@ -337,34 +337,64 @@ __device__ __forceinline__ void store_layer(char* actb, const f32x16 (&acc)[Geo<
     }
 }
 
-// ================================ fine-tile path (3-board workgroups) ================================================
-// Same workgroup (8 waves: 2 position groups x 4 cout groups), same LDS layout, same arithmetic -- but 16-row tiles (v_mfma_f32_16x16x4_f32: 16 positions x 16 couts
-// x 4 input channels, 32 cycles, the same FLOP rate as the 32x32x2 form).  With 16 tiles instead of 8 the 243 board
-// points can be grouped by edge class, so more all-zero-halo taps are skipped: per wave (wm = 0 / 1) the 8 tiles are
-//     [ x-edge | 5 interior | y-edge a | y-edge b ]     x-edge: 16 points with x = 0 (wm 0) / x = 8 (wm 1), y in 1..7
-//                                                        y-edge: the 27 points with y = 0 / y = 8 (+ 5 padding rows)
-//                                                        interior: the rest (+ 3 padding rows at the very end)
-// and a tap skips the x-edge tile when dx points off the board for it, the two y-edge tiles when dy does: the active
-// tiles are always a contiguous range [LO, HI), LO in {0,1}, HI in {6,8}.  3x3 layers: 63 of 72 tile-taps (coarse
-// path: 66 of 72 in 32-row units), layer 0: 170 of 200 (coarse: 180): 4.6 % fewer MFMA cycles.
+// ================================ fine-tile path (2- and 3-board workgroups) ===========================================
+// Same workgroup (8 waves, two per SIMD), same LDS layout, same arithmetic -- but 16-row tiles
+// (v_mfma_f32_16x16x4_f32: 16 positions x 16 couts x 4 input channels, 32 cycles, the same FLOP rate as the 32x32x2
+// form).  With 16-row tiles the board points can be grouped by edge class, so more all-zero-halo taps are skipped:
+//   3 boards (243 points, 16 tiles): two position groups (wm = 0 / 1) x four cout groups; a wave = 8 tiles x 2 cout tiles
+//       [ x-edge | 5 interior | y-edge a | y-edge b ]    x-edge: 16 of the 21 points with x = 0 (wm 0) / x = 8 (wm 1), y in 1..7
+//                                                         y-edge: the 27 points with y = 0 / y = 8 (+ 5 padding rows)
+//                                                         interior: the rest (+ 3 padding rows at the very end)
+//       3x3 layers: 63 of 72 tile-taps (32-row form: 66 of 72 in 32-row units), layer 0: 170 of 200 (180): -4.6 % MFMA cycles
+//   2 boards (162 points, 11 tiles instead of six 32-row tiles = 12): one position group x eight cout groups; a wave = 11
+//       tiles x 1 cout tile   [ x=0 | x=8 | 7 interior | y=0 | y=8 ]   (14 / 14 / 98 + 4 left over / 16 / 16 points)
+//       3x3 layers: 87 of 99 tile-taps against 108 (12 x 9) in 16-row units for the 32-row form: -19 %
+// A tap skips an edge tile when it points off the board for every point of the tile (wave-uniform branch).
 // Channels: an MFMA k-step consumes 4 input channels, one per lane quad kq, and a lane's accumulator holds 4
 // consecutive output slots.  Outputs of layers 0..5 are kept in the slot order bk_fine_perm (bk_internal.h), which makes
-// the k order of every dot product equal to the coarse path's (8-channel groups, pairs (j, j+4)): the two paths agree
+// the k order of every dot product equal to the 32-row form's (8-channel groups, pairs (j, j+4)): the two forms agree
 // BIT FOR BIT.  Layer 6 writes natural channel order for the heads.  The host packs weights and biases accordingly.
+template <int NB>
+struct Fine {
+    static_assert(NB == 2 || NB == 3, "fine tiles are laid out for 2- and 3-board workgroups");
+    static constexpr int WM = NB == 3 ? 2 : 1;          // position groups
+    static constexpr int WN = 8 / WM;                   // cout groups
+    static constexpr int RT = NB == 3 ? 8 : 11;         // 16-position tiles per wave
+    static constexpr int CTW = 8 / WN;                  // 16-cout tiles per wave
+    // tile classes of a wave: [A0, A1) always; X0 skips when dx < 0 resp. (NB == 3, wm == 1) dx > 0; X1 (NB == 2) when
+    // dx > 0; [Y0a, Y0b) when dy < 0 resp. (NB == 3, wm == 1) dy > 0; Y1 (NB == 2) when dy > 0
+    static constexpr int A0 = NB == 3 ? 1 : 2, A1 = NB == 3 ? 6 : 9;
+    static constexpr int X0 = 0, X1 = NB == 3 ? -1 : 1;
+    static constexpr int Y0a = NB == 3 ? 6 : 9, Y0b = NB == 3 ? 8 : 10, Y1 = NB == 3 ? -1 : 10;
+};
 struct FineRow { int b, y, x; bool valid; };
+template <int NB>
 __device__ __forceinline__ FineRow fine_row(int wm, int rt, int p16) {
     FineRow r{0, 4, 0, true};
-    if (rt == 0) {                       // x-edge tile: the first 16 of the 21 points (b, y = 1..7, x = 0 or 8)
-        r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = wm ? 8 : 0;
-    } else if (rt <= 5) {                // interior pool: 147 interior points, then the 5 + 5 x-edge points left over
-        const int i = wm * 80 + (rt - 1) * 16 + p16;
-        if (i < 147) { r.b = i / 49; const int rem = i - 49 * r.b; r.y = 1 + rem / 7; r.x = 1 + rem % 7; }
-        else if (i < 157) { const int jx = 16 + (i - 147) % 5; r.b = jx / 7; r.y = 1 + jx % 7; r.x = i < 152 ? 0 : 8; }
-        else r.valid = false;
-    } else {                             // y-edge tiles: (b, y = 0 or 8, x = 0..8)
-        const int i = (rt - 6) * 16 + p16;
-        if (i < 27) { r.b = i / 9; r.x = i % 9; r.y = wm ? 8 : 0; }
-        else r.valid = false;
+    if constexpr (NB == 3) {
+        if (rt == 0) {                       // x-edge tile: the first 16 of the 21 points (b, y = 1..7, x = 0 or 8)
+            r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = wm ? 8 : 0;
+        } else if (rt <= 5) {                // interior pool: 147 interior points, then the 5 + 5 x-edge points left over
+            const int i = wm * 80 + (rt - 1) * 16 + p16;
+            if (i < 147) { r.b = i / 49; const int rem = i - 49 * r.b; r.y = 1 + rem / 7; r.x = 1 + rem % 7; }
+            else if (i < 157) { const int jx = 16 + (i - 147) % 5; r.b = jx / 7; r.y = 1 + jx % 7; r.x = i < 152 ? 0 : 8; }
+            else r.valid = false;
+        } else {                             // y-edge tiles: (b, y = 0 or 8, x = 0..8)
+            const int i = (rt - 6) * 16 + p16;
+            if (i < 27) { r.b = i / 9; r.x = i % 9; r.y = wm ? 8 : 0; }
+            else r.valid = false;
+        }
+    } else {
+        if (rt <= 1) {                       // x = 0 / x = 8 tiles: the 14 points (b, y = 1..7) + 2 padding rows
+            if (p16 < 14) { r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = rt ? 8 : 0; } else r.valid = false;
+        } else if (rt <= 8) {                // interior pool: 98 interior points, then the 2 + 2 y-edge points left over
+            const int i = (rt - 2) * 16 + p16;
+            if (i < 98) { r.b = i / 49; const int rem = i - 49 * r.b; r.y = 1 + rem / 7; r.x = 1 + rem % 7; }
+            else if (i < 102) { r.b = 1; r.x = 7 + (i & 1); r.y = i < 100 ? 0 : 8; }   // entries 16, 17 of the y-edge lists
+            else r.valid = false;
+        } else {                             // y = 0 / y = 8 tiles: the first 16 of the 18 points (b, x = 0..8)
+            r.b = p16 / 9; r.x = p16 % 9; r.y = rt == 9 ? 0 : 8;
+        }
     }
     if (!r.valid) { r.b = 0; r.y = 4; r.x = 0; }   // padding rows compute from a valid address; stored to the dummy record
     return r;
@@ -381,87 +411,85 @@ __device__ __forceinline__ int in_slot_fine(int c) {
 // "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
 // PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
 // after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
-template <bool FIRST, bool PRELOADED>
-__device__ __forceinline__ void conv_layer_fine(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[8][2],
-                                                int lane, int wm, int wn, const int (&rowa)[8], f32x4 (&W0)[2],
-                                                f32x4 (&W1)[2], f32x4 (&W2)[2], f32x4 (&W3)[2]) {
+template <int NB, bool FIRST, bool PRELOADED>
+__device__ __forceinline__ void conv_layer_fine(const char* actb, const float* __restrict__ wl,
+                                                f32x4 (&acc)[Fine<NB>::RT][Fine<NB>::CTW], int lane, int wm, int wn,
+                                                const int (&rowa)[Fine<NB>::RT], f32x4 (&W0)[Fine<NB>::CTW],
+                                                f32x4 (&W1)[Fine<NB>::CTW], f32x4 (&W2)[Fine<NB>::CTW],
+                                                f32x4 (&W3)[Fine<NB>::CTW]) {
+    using F = Fine<NB>;
+    constexpr int RT = F::RT, CTW = F::CTW;
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
     constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
-    const char* ap[8];
+    const char* ap[RT];
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) ap[rt] = actb + rowa[rt];
+    for (int rt = 0; rt < RT; ++rt) ap[rt] = actb + rowa[rt];
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // this wave's 2 cout tiles (2*wn, 2*wn+1 of 8): 1 KiB per tile and group, 8 KiB per group
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + wn * 2 * 256), 0, 0x7ffffff0, 0x00020000);
+    // this wave's cout tiles (CTW*wn ..): 1 KiB per tile and group, 8 KiB per group
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + wn * CTW * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
     int boff = PRELOADED ? 2 * 8192 : 0;                // scalar: byte offset of the group being fetched
-    auto load_w = [&](f32x4 (&W)[2]) {
+    auto load_w = [&](f32x4 (&W)[CTW]) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CTW; ++ct)
             W[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16 + ct * 1024, boff, 0));
         boff += 8192;
     };
-    auto read_a = [&](f32x4 (&A)[8], int imm) {
+    auto read_a = [&](f32x4 (&A)[RT], int imm) {
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
+        for (int rt = 0; rt < RT; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
     };
-    f32x4 A0[8], A1[8];                                 // activations: ping-pong per group (weights: ring, 2 groups ahead)
+    f32x4 A0[RT], A1[RT];                               // activations: ping-pong per group (weights: ring, 2 groups ahead)
 
-    // one group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
-    // taps: the five interior tiles always run; the x-edge tile (0) and the two y-edge tiles (6, 7) sit behind
-    // wave-uniform branches (four specialised copies of the tap body -- 33 KB of straight-line MFMAs -- thrashed the
-    // instruction cache: 34.2 cycles per MFMA instead of 32)
-    auto do_group = [&](auto GIc, f32x4 (&Wc)[2], f32x4 (&Wn)[2], int delta, bool skip_x, bool skip_y) {
+    // One group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
+    // taps: the interior tiles always run, every edge tile sits behind a wave-uniform branch (specialised copies of the
+    // tap body -- tens of KB of straight-line MFMAs -- were measured slower).  sx0/sx1/sy0/sy1: skip that edge class.
+    auto do_group = [&](auto GIc, f32x4 (&Wc)[CTW], f32x4 (&Wn)[CTW], int delta, bool sx0, bool sx1, bool sy0, bool sy1) {
         constexpr int g = decltype(GIc)::value;
         constexpr int JN = (FIRST && g == 1) ? 3 : 4;   // layer 0: planes 16..26 take 3 k-steps
-        f32x4 (&Ac)[8] = (g & 1) ? A1 : A0;
-        f32x4 (&An)[8] = (g & 1) ? A0 : A1;
+        f32x4 (&Ac)[RT] = (g & 1) ? A1 : A0;
+        f32x4 (&An)[RT] = (g & 1) ? A0 : A1;
+        auto tiles = [&](int j0, int j1, auto T0, auto T1) {
+#pragma unroll
+            for (int j = j0; j < j1; ++j)
+#pragma unroll
+                for (int rt = decltype(T0)::value; rt < decltype(T1)::value; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        };
+        using IC = std::integral_constant<int, 0>;
+        (void)IC{};
         load_w(Wn);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt = 1; rt < 6; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][0], Ac[rt][0], acc[rt][ct], 0, 0, 0);
+        tiles(0, 1, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
         if (g == G - 1) {                               // next group is group 0 of the next tap
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) ap[rt] += delta;
+            for (int rt = 0; rt < RT; ++rt) ap[rt] += delta;
             read_a(An, 0);
         } else {
             read_a(An, (g + 1) * 64);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 1; j < JN; ++j)
-#pragma unroll
-            for (int rt = 1; rt < 6; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        tiles(1, JN, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (!skip_x) {
-#pragma unroll
-            for (int j = 0; j < JN; ++j)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[0][j], acc[0][ct], 0, 0, 0);
+        if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (F::X1 >= 0) {
+            if (!sx1) tiles(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (!skip_y) {
-#pragma unroll
-            for (int j = 0; j < JN; ++j)
-#pragma unroll
-                for (int rt = 6; rt < 8; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+        if constexpr (F::Y1 >= 0) {
+            if (!sy1) tiles(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -475,25 +503,27 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
     auto tap = [&](auto PHc, int t) {
         const int ky = t / KW, kx = t - ky * KW;
         const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
-        const bool sx = wm == 0 ? kx < KW / 2 : kx > KW / 2;   // this wave's x-edge tile reads only zero halo
-        const bool sy = wm == 0 ? ky < KW / 2 : ky > KW / 2;   // ... its two y-edge tiles do
+        const bool lo_x = kx < KW / 2, hi_x = kx > KW / 2, lo_y = ky < KW / 2, hi_y = ky > KW / 2;
+        // 3 boards: a wave's x-edge tile holds x = 0 (wm 0) or x = 8 (wm 1) points, its y-edge tiles y = 0 or y = 8
+        const bool sx0 = NB == 3 ? (wm == 0 ? lo_x : hi_x) : lo_x, sx1 = hi_x;
+        const bool sy0 = NB == 3 ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
         if constexpr (FIRST) {
             if constexpr (decltype(PHc)::value == 0) {
-                do_group(I0{}, W0, W2, d, sx, sy);
-                do_group(I1{}, W1, W3, d, sx, sy);
+                do_group(I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
+                do_group(I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
             } else {
-                do_group(I0{}, W2, W0, d, sx, sy);
-                do_group(I1{}, W3, W1, d, sx, sy);
+                do_group(I0{}, W2, W0, d, sx0, sx1, sy0, sy1);
+                do_group(I1{}, W3, W1, d, sx0, sx1, sy0, sy1);
             }
         } else {
-            do_group(I0{}, W0, W2, d, sx, sy);
-            do_group(I1{}, W1, W3, d, sx, sy);
-            do_group(I2{}, W2, W0, d, sx, sy);
-            do_group(I3{}, W3, W1, d, sx, sy);
-            do_group(I4{}, W0, W2, d, sx, sy);
-            do_group(I5{}, W1, W3, d, sx, sy);
-            do_group(I6{}, W2, W0, d, sx, sy);
-            do_group(I7{}, W3, W1, d, sx, sy);
+            do_group(I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
+            do_group(I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
+            do_group(I2{}, W2, W0, d, sx0, sx1, sy0, sy1);
+            do_group(I3{}, W3, W1, d, sx0, sx1, sy0, sy1);
+            do_group(I4{}, W0, W2, d, sx0, sx1, sy0, sy1);
+            do_group(I5{}, W1, W3, d, sx0, sx1, sy0, sy1);
+            do_group(I6{}, W2, W0, d, sx0, sx1, sy0, sy1);
+            do_group(I7{}, W3, W1, d, sx0, sx1, sy0, sy1);
         }
     };
 
@@ -515,13 +545,15 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
     }
 }
 
-// bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 32*wn + 16*ct + 4*kq .. +3 of its position
-__device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[8][2], const f32x4 (&bv)[2], const int (&storea)[8]) {
+// bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 16*(CTW*wn + ct) + 4*kq .. +3 of its position
+template <int NB>
+__device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[Fine<NB>::RT][Fine<NB>::CTW],
+                                                 const f32x4 (&bv)[Fine<NB>::CTW], const int (&storea)[Fine<NB>::RT]) {
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
+    for (int rt = 0; rt < Fine<NB>::RT; ++rt) {
         char* wp = actb + storea[rt];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < Fine<NB>::CTW; ++ct) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][ct][e] + bv[ct][e], 0.f);
@@ -529,9 +561,10 @@ __device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[
         }
     }
 }
-__device__ __forceinline__ void load_bias_fine(f32x4 (&bv)[2], const float* __restrict__ biasF, int wn, int kq) {
+template <int NB>
+__device__ __forceinline__ void load_bias_fine(f32x4 (&bv)[Fine<NB>::CTW], const float* __restrict__ biasF, int wn, int kq) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(biasF + 32 * wn + 16 * ct + 4 * kq);
+    for (int ct = 0; ct < Fine<NB>::CTW; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(biasF + 16 * (Fine<NB>::CTW * wn + ct) + 4 * kq);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -551,7 +584,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // FINE: the 16-row-tile form of the conv layers (3-board workgroups only), see conv_layer_fine
 template <int NB, bool GATED, bool FINE>
 __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk_eval_args a) {
-    static_assert(!FINE || (NB == 3 && Geo<NB>::NW == 8 && Geo<NB>::WM == 2), "the fine-tile path is laid out for 8-wave 3-board workgroups");
+    static_assert(!FINE || ((NB == 2 || NB == 3) && Geo<NB>::NW == 8), "the fine-tile path is laid out for 8-wave 2- and 3-board workgroups");
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
@@ -588,13 +621,15 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 
     STAMP(0);
     // weight ping-pong buffers (see conv_layer); layer 0's first block is requested before the input staging
-    const int wm = wave / G::WN, wn = wave - wm * G::WN;
+    constexpr int kWN = FINE ? 8 / (NB == 3 ? 2 : 1) : G::WN;   // cout groups of the wave grid (the fine form has its own)
+    const int wm = wave / kWN, wn = wave - wm * kWN;
     f32x4 Bw0[4][G::NT], Bw1[4][G::NT];
-    f32x4 Wr0[2], Wr1[2], Wr2[2], Wr3[2];   // fine path: the weight ring (see conv_layer_fine)
+    constexpr int kCTW = NB == 3 ? 2 : 1;
+    f32x4 Wr0[kCTW], Wr1[kCTW], Wr2[kCTW], Wr3[kCTW];   // fine path: the weight ring (see conv_layer_fine)
     if constexpr (FINE) {
-        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfragF + wn * 2 * 256), 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfragF + wn * kCTW * 256), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < kCTW; ++ct) {
             Wr0[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 0, 0));
             Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
         }
@@ -646,42 +681,48 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 
     STAMP(1);
     if constexpr (FINE) {
+        using F = Fine<NB == 1 ? 3 : NB>;
+        constexpr int RT = F::RT;
         const int kq = lane >> 4;
-        f32x4 acc[8][2];
-        // this lane's 8 positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
-        // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's 32 couts)
-        int rowa0[8], rowa3[8], storea[8];
+        f32x4 acc[RT][F::CTW];
+        // this lane's positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
+        // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's couts)
+        int rowa0[RT], rowa3[RT], storea[RT];
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-            const FineRow fr = fine_row(wm, rt, lane & 15);
+        for (int rt = 0; rt < RT; ++rt) {
+            const FineRow fr = fine_row<NB == 1 ? 3 : NB>(wm, rt, lane & 15);
             rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
             rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
-            storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (32 * wn + 4 * kq) * 4 : dummy_byte;
+            storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
         }
-        f32x4 bv[2];
-        load_bias_fine(bv, P.biasF, wn, kq);
-        conv_layer_fine<true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
+        f32x4 bv[F::CTW];
+        load_bias_fine<NB == 1 ? 3 : NB>(bv, P.biasF, wn, kq);
+        conv_layer_fine<NB == 1 ? 3 : NB, true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
         STAMP(2);
         __syncthreads();  // everyone done reading the input planes
-        for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {   // clear the 38 halo records (see the coarse path)
-            const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
-            const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
-            *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NB == 3) {
+            for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {   // clear the 38 halo records (see the 32-row form)
+                const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
+                const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
+                *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            for (int i = tid; i < G::L3_BYTES / 16; i += G::THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         STAMP(3);
-        store_layer_fine(actb, acc, bv, storea);
+        store_layer_fine<NB == 1 ? 3 : NB>(actb, acc, bv, storea);
         STAMP(4);
         __syncthreads();
         STAMP(5);
 #pragma unroll 1
         for (int L = 1; L < 7; ++L) {
-            load_bias_fine(bv, P.biasF + L * 128, wn, kq);
-            conv_layer_fine<false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+            load_bias_fine<NB == 1 ? 3 : NB>(bv, P.biasF + L * 128, wn, kq);
+            conv_layer_fine<NB == 1 ? 3 : NB, false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
             STAMP(2 + 4 * L);
             __syncthreads();
             STAMP(3 + 4 * L);
-            store_layer_fine(actb, acc, bv, storea);
+            store_layer_fine<NB == 1 ? 3 : NB>(actb, acc, bv, storea);
             STAMP(4 + 4 * L);
             __syncthreads();
             STAMP(5 + 4 * L);
@@ -822,10 +863,10 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
 // the CUs) x (time of one round of nb-board workgroups, one per CU).  NB=1 workgroups are small enough to sit two per
 // CU but then share the pipes, so that buys nothing here.
 //   f16x2: measured round times 86 : 150 : 195 us
-//   fp32:  the MFMA count sets the time: 3 / 6 / 8 row tiles, the 3-board form skipping 8 % of its MFMAs (zero-halo
-//          taps): 0.41 : 0.82 : 1
+//   fp32:  measured round times 0.33 : 0.55 : 0.754 ms (1 board: 32-row tiles, 4 waves; 2 and 3 boards: fine tiles,
+//          8 waves)
 long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision) {
-    static const int t16[4] = {0, 44, 77, 100}, t32[4] = {0, 41, 82, 100};
+    static const int t16[4] = {0, 44, 77, 100}, t32[4] = {0, 44, 73, 100};
     const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
     return (wgs + n_cu - 1) / n_cu * (precision == BK_PRECISION_F16X2 ? t16 : t32)[nb];
 }
@@ -845,18 +886,18 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
 }
 
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {
-    // 3-board workgroups run the fine-tile form; BK_FP32_COARSE=1 selects the 32-row-tile form (same bits) for A/B runs
+    // 2- and 3-board workgroups run the fine-tile form; BK_FP32_COARSE=1 selects the 32-row-tile form (same bits) for A/B runs
     static const bool fine = getenv("BK_FP32_COARSE") == nullptr;
     if (a.gate) {
         switch (nb) {
             case 1: return launch_nb<1, true, false>(a, stream);
-            case 2: return launch_nb<2, true, false>(a, stream);
+            case 2: return fine ? launch_nb<2, true, true>(a, stream) : launch_nb<2, true, false>(a, stream);
             default: return fine ? launch_nb<3, true, true>(a, stream) : launch_nb<3, true, false>(a, stream);
         }
     }
     switch (nb) {
         case 1: return launch_nb<1, false, false>(a, stream);
-        case 2: return launch_nb<2, false, false>(a, stream);
+        case 2: return fine ? launch_nb<2, false, true>(a, stream) : launch_nb<2, false, false>(a, stream);
         default: return fine ? launch_nb<3, false, true>(a, stream) : launch_nb<3, false, false>(a, stream);
     }
 }
