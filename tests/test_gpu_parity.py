@@ -410,3 +410,26 @@ def test_sweep_worst_cases_vs_reference(precision, wset):
     # no further from the float64 ground truth than 2x the reference's own fp32 rounding
     ref_noise = np.abs(lg - w[f"logits_f64_{wset}"]).max()
     assert np.abs(out["logits"] - w[f"logits_f64_{wset}"]).max() < 2 * ref_noise + 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_every_workgroup_size_gives_the_same_bits(precision, monkeypatch):
+    """1-, 2- and 3-board workgroups (BK_FORCE_NB) are three different code paths -- for fp32 the 1-board form uses
+    32-row MFMA tiles and 4 waves, the 2- and 3-board forms 16-row tiles with edge-class tap skipping, permuted channel
+    slots and 8 waves -- and must agree bit for bit on every output, for ragged batch sizes and policy prefixes."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(700, seed_base=123_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=1024, precision=precision)
+    monkeypatch.setenv("BK_NO_SPLIT", "1")
+    outs = {}
+    for nb in (1, 2, 3):
+        monkeypatch.setenv("BK_FORCE_NB", str(nb))
+        outs[nb] = [eng.eval(x[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
+                    for B, npol in ((1, 1), (2, 2), (5, 3), (82, 1), (163, 163), (700, 700), (697, 50))]
+    eng.close()
+    for nb in (2, 3):
+        for a, b in zip(outs[1], outs[nb]):
+            for k in b:
+                assert np.array_equal(a[k], b[k]), (nb, k)
