@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "bk_internal.h"
 
@@ -354,6 +355,21 @@ __device__ __forceinline__ void store_layer(char* actb, const f32x16 (&acc)[Geo<
 // consecutive output slots.  Outputs of layers 0..5 are kept in the slot order bk_fine_perm (bk_internal.h), which makes
 // the k order of every dot product equal to the 32-row form's (8-channel groups, pairs (j, j+4)): the two forms agree
 // BIT FOR BIT.  Layer 6 writes natural channel order for the heads.  The host packs weights and biases accordingly.
+// Scheduling of the fine path, measured on one box (leaf-evals/s at B = 4,096): hard sched_barrier fences between the
+// phases of a channel group 506.9 k; none (the compiler's own order) 510.4 k; none + the pattern hint below 511.9 k.
+#ifdef BK_FINE_FENCES
+#define FINE_SB __builtin_amdgcn_sched_barrier(0)
+#else
+#define FINE_SB do {} while (0)
+#endif
+// scheduling hint for one channel group: NMFMA matrix instructions with NREADS LDS reads and NLOADS weight loads dealt out
+// between them.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
+template <int NMFMA, int NREADS, int NLOADS, int... I>
+__device__ __forceinline__ void fine_sched_pattern(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NREADS + (I < NMFMA % NREADS ? 1 : 0), 0),
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0), __builtin_amdgcn_sched_group_barrier(0x020, I < NLOADS ? 1 : 0, 0)),
+     ...);
+}
 template <int NB>
 struct Fine {
     static_assert(NB == 2 || NB == 3, "fine tiles are laid out for 2- and 3-board workgroups");
@@ -466,7 +482,7 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         using IC = std::integral_constant<int, 0>;
         (void)IC{};
         load_w(Wn);
-        __builtin_amdgcn_sched_barrier(0);
+        FINE_SB;
         tiles(0, 1, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
         if (g == G - 1) {                               // next group is group 0 of the next tap
 #pragma unroll
@@ -475,20 +491,24 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         } else {
             read_a(An, (g + 1) * 64);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        FINE_SB;
         tiles(1, JN, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef BK_FINE_FENCES
+        // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs
+        fine_sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
+#endif
+        FINE_SB;
         if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
-        __builtin_amdgcn_sched_barrier(0);
+        FINE_SB;
         if constexpr (F::X1 >= 0) {
             if (!sx1) tiles(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
+            FINE_SB;
         }
         if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
-        __builtin_amdgcn_sched_barrier(0);
+        FINE_SB;
         if constexpr (F::Y1 >= 0) {
             if (!sy1) tiles(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
+            FINE_SB;
         }
     };
     using I0 = std::integral_constant<int, 0>;
