@@ -87,21 +87,17 @@ struct Geo {
     // waits (65.06 cycles per MFMA, limit 64); with two waves per SIMD (8: each owns all its row group's position tiles
     // and ONE 32-cout tile) the other wave's MFMA fills the slot: +1.1 % measured, bit-identical.  Measured and
     // rejected: 8 waves as 4 position groups x 2 cout groups (+0.5 %), 16 waves as 4 x 4 (+0.4 %).
-    // The 1-board form keeps 4 waves (3 position tiles do not split in two).
 #ifndef BK_FP32_NW2
 #define BK_FP32_NW2 8
 #endif
 #ifndef BK_FP32_NW3
 #define BK_FP32_NW3 8
 #endif
-#ifndef BK_FP32_NW1
-#define BK_FP32_NW1 4
-#endif
-    static constexpr int NW = NB == 1 ? BK_FP32_NW1 : NB == 2 ? BK_FP32_NW2 : BK_FP32_NW3;
+    static constexpr int NW = 8;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int WM = NW == 12 ? 3 : (MT % 2 == 0) ? 2 : 1;   // 12 waves: the 1-board form, one wave per (position tile, cout tile)
+    static constexpr int WM = (MT % 2 == 0) ? 2 : 1;
     static constexpr int WN = NW / WM;
-    static constexpr int NT = 4 / WN;
+    static constexpr int NT = WN > 4 ? 1 : 4 / WN;      // (the 32-row form does not exist for 1 board x 8 waves: fine tiles only)
     static constexpr int MTW = MT / WM;
     static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one shared record: never read)
     static constexpr int HS_FLOATS = NB * 96;
@@ -372,22 +368,26 @@ __device__ __forceinline__ void fine_sched_pattern(std::integer_sequence<int, I.
 }
 template <int NB>
 struct Fine {
-    static_assert(NB == 2 || NB == 3, "fine tiles are laid out for 2- and 3-board workgroups");
+    static_assert(NB >= 1 && NB <= 3, "fine tiles are laid out for 1-, 2- and 3-board workgroups");
     static constexpr int WM = NB == 3 ? 2 : 1;          // position groups
     static constexpr int WN = 8 / WM;                   // cout groups
-    static constexpr int RT = NB == 3 ? 8 : 11;         // 16-position tiles per wave
+    static constexpr int RT = NB == 3 ? 8 : NB == 2 ? 11 : 6;   // 16-position tiles per wave
     static constexpr int CTW = 8 / WN;                  // 16-cout tiles per wave
     // tile classes of a wave: [A0, A1) always; X0 skips when dx < 0 resp. (NB == 3, wm == 1) dx > 0; X1 (NB == 2) when
-    // dx > 0; [Y0a, Y0b) when dy < 0 resp. (NB == 3, wm == 1) dy > 0; Y1 (NB == 2) when dy > 0
-    static constexpr int A0 = NB == 3 ? 1 : 2, A1 = NB == 3 ? 6 : 9;
-    static constexpr int X0 = 0, X1 = NB == 3 ? -1 : 1;
-    static constexpr int Y0a = NB == 3 ? 6 : 9, Y0b = NB == 3 ? 8 : 10, Y1 = NB == 3 ? -1 : 10;
+    // dx > 0; [Y0a, Y0b) when dy < 0 resp. (NB == 3, wm == 1) dy > 0; Y1 (NB == 2) when dy > 0; -1: no such tile
+    // (1 board: 81 points in 6 tiles, too few per edge class to fill a tile: every tile runs every tap)
+    static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 6;
+    static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
+    static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
 };
 struct FineRow { int b, y, x; bool valid; };
 template <int NB>
 __device__ __forceinline__ FineRow fine_row(int wm, int rt, int p16) {
     FineRow r{0, 4, 0, true};
-    if constexpr (NB == 3) {
+    if constexpr (NB == 1) {
+        const int i = rt * 16 + p16;
+        if (i < 81) { r.y = i / 9; r.x = i % 9; } else r.valid = false;
+    } else if constexpr (NB == 3) {
         if (rt == 0) {                       // x-edge tile: the first 16 of the 21 points (b, y = 1..7, x = 0 or 8)
             r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = wm ? 8 : 0;
         } else if (rt <= 5) {                // interior pool: 147 interior points, then the 5 + 5 x-edge points left over
@@ -498,14 +498,18 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         fine_sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
 #endif
         FINE_SB;
-        if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
-        FINE_SB;
+        if constexpr (F::X0 >= 0) {
+            if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
+            FINE_SB;
+        }
         if constexpr (F::X1 >= 0) {
             if (!sx1) tiles(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
             FINE_SB;
         }
-        if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
-        FINE_SB;
+        if constexpr (F::Y0a >= 0) {
+            if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
+            FINE_SB;
+        }
         if constexpr (F::Y1 >= 0) {
             if (!sy1) tiles(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
             FINE_SB;
@@ -604,7 +608,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // FINE: the 16-row-tile form of the conv layers (3-board workgroups only), see conv_layer_fine
 template <int NB, bool GATED, bool FINE>
 __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk_eval_args a) {
-    static_assert(!FINE || ((NB == 2 || NB == 3) && Geo<NB>::NW == 8), "the fine-tile path is laid out for 8-wave 2- and 3-board workgroups");
+    static_assert(FINE || NB > 1, "1-board workgroups exist in the fine-tile form only");
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 
     STAMP(1);
     if constexpr (FINE) {
-        using F = Fine<NB == 1 ? 3 : NB>;
+        using F = Fine<NB>;
         constexpr int RT = F::RT;
         const int kq = lane >> 4;
         f32x4 acc[RT][F::CTW];
@@ -710,14 +714,14 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         int rowa0[RT], rowa3[RT], storea[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const FineRow fr = fine_row<NB == 1 ? 3 : NB>(wm, rt, lane & 15);
+            const FineRow fr = fine_row<NB>(wm, rt, lane & 15);
             rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
             rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
             storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
         }
         f32x4 bv[F::CTW];
-        load_bias_fine<NB == 1 ? 3 : NB>(bv, P.biasF, wn, kq);
-        conv_layer_fine<NB == 1 ? 3 : NB, true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
+        load_bias_fine<NB>(bv, P.biasF, wn, kq);
+        conv_layer_fine<NB, true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
         STAMP(2);
         __syncthreads();  // everyone done reading the input planes
         if constexpr (NB == 3) {
@@ -731,18 +735,18 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         }
         __syncthreads();
         STAMP(3);
-        store_layer_fine<NB == 1 ? 3 : NB>(actb, acc, bv, storea);
+        store_layer_fine<NB>(actb, acc, bv, storea);
         STAMP(4);
         __syncthreads();
         STAMP(5);
 #pragma unroll 1
         for (int L = 1; L < 7; ++L) {
-            load_bias_fine<NB == 1 ? 3 : NB>(bv, P.biasF + L * 128, wn, kq);
-            conv_layer_fine<NB == 1 ? 3 : NB, false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+            load_bias_fine<NB>(bv, P.biasF + L * 128, wn, kq);
+            conv_layer_fine<NB, false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
             STAMP(2 + 4 * L);
             __syncthreads();
             STAMP(3 + 4 * L);
-            store_layer_fine<NB == 1 ? 3 : NB>(actb, acc, bv, storea);
+            store_layer_fine<NB>(actb, acc, bv, storea);
             STAMP(4 + 4 * L);
             __syncthreads();
             STAMP(5 + 4 * L);
@@ -910,13 +914,13 @@ hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream
     static const bool fine = getenv("BK_FP32_COARSE") == nullptr;
     if (a.gate) {
         switch (nb) {
-            case 1: return launch_nb<1, true, false>(a, stream);
+            case 1: return launch_nb<1, true, true>(a, stream);
             case 2: return fine ? launch_nb<2, true, true>(a, stream) : launch_nb<2, true, false>(a, stream);
             default: return fine ? launch_nb<3, true, true>(a, stream) : launch_nb<3, true, false>(a, stream);
         }
     }
     switch (nb) {
-        case 1: return launch_nb<1, false, false>(a, stream);
+        case 1: return launch_nb<1, false, true>(a, stream);
         case 2: return fine ? launch_nb<2, false, true>(a, stream) : launch_nb<2, false, false>(a, stream);
         default: return fine ? launch_nb<3, false, true>(a, stream) : launch_nb<3, false, false>(a, stream);
     }
