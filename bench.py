@@ -39,8 +39,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md chip table (dense f16
 BYTES_PER_LEAF = 8748 + 328          # compulsory HBM bytes (f32 planes in, 81 probs + value out)
 BATCH = 4096
 TOL = {"logit": 1e-4, "prob": 1e-5, "value": 1e-4}   # BASELINE.json north_star / SURVEY 8d config 1
-KERNEL = {"f32": "bk_leaf_eval_kernel<3, false, true> (+ its <2, false, true> tail launch: one step = 10 rounds of 3-board "
-                 "workgroups + 1 of 2-board ones)",
+KERNEL = {"f32": "bk_leaf_eval_kernel<3, false> (+ its <2, false> tail launch: one step = 10 rounds of 3-board workgroups "
+                 "+ 1 of 2-board ones)",
           "f16x2": "bk_leaf_eval_f16_kernel<3>"}
 DTYPE = {"f32": "f32", "f16x2": "f16x2 (fp16 hi/lo split operands = 22-bit significands, fp32 accumulate)"}
 

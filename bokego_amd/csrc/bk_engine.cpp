@@ -94,47 +94,15 @@ bool trunk_ok(const bk_trunk_weights& t) {
     return t.head_w && t.head_b;
 }
 
-// Fold BatchNorm2d (eval) into conv l and emit the MFMA fragment order consumed by conv_layer<>
-// in bk_kernels.hip:
-//   index = (((tap*G + g)*4 + ntile)*64 + lane)*4 + j
-//   cout = 32*ntile + (lane&31), cin = 8g + 4(lane>>5) + j, tap = ky*K + kx
-//   (layer 0, g = 3: cin = 24 + 2j + (lane>>5) for j < 2, nothing for j >= 2: 27 channels in 14 k-steps of 2)
-void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
-    wfrag.assign(BK_WFRAG_FLOATS + BK_WFRAG_PAD_FLOATS, 0.f);
-    bias.assign(7 * 128, 0.f);
-    size_t base = 0;
-    for (int l = 0; l < 7; ++l) {
-        const int K = l == 0 ? 5 : 3, cin = l == 0 ? 27 : 128, G = l == 0 ? 4 : 16, TAPS = K * K;
-        std::vector<double> scale(128);
-        for (int co = 0; co < 128; ++co) {
-            scale[co] = (double)t.bn_w[l][co] / std::sqrt((double)t.bn_var[l][co] + kBnEps);
-            bias[l * 128 + co] = (float)(((double)t.conv_b[l][co] - (double)t.bn_mean[l][co]) * scale[co] + (double)t.bn_b[l][co]);
-        }
-        for (int tp = 0; tp < TAPS; ++tp)
-            for (int g = 0; g < G; ++g)
-                for (int nt = 0; nt < 4; ++nt)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int co = 32 * nt + (lane & 31);
-                            int ci = 8 * g + 4 * (lane >> 5) + j;
-                            // layer 0: the last group holds channels 24..26 in two k-steps (bk_kernels.hip in_slot())
-                            if (l == 0 && g == 3) ci = j < 2 ? 24 + 2 * j + (lane >> 5) : cin;
-                            float v = 0.f;
-                            if (ci < cin) v = (float)((double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co]);
-                            wfrag[base + ((((size_t)tp * G + g) * 4 + nt) * 64 + lane) * 4 + j] = v;
-                        }
-        base += (size_t)TAPS * G * 1024;
-    }
-}
-
-// Fine-tile fp32 path (conv_layer_fine<> in bk_kernels.hip, v_mfma_f32_16x16x4_f32, weights = A operand):
+// Fold BatchNorm2d (eval) into conv l and emit the MFMA fragment order consumed by conv_layer<> in bk_kernels.hip
+// (v_mfma_f32_16x16x4_f32, weights = A operand):
 //   index = (((tap*G + g)*8 + ctile)*64 + lane)*4 + j,   G = 2 (layer 0) / 8 groups of 16 input slots
 //   MFMA row r = lane & 15 of cout tile ctile holds output SLOT 16*ctile + r; lane quad kq = lane >> 4 and k-step j
-//   consume input SLOT 16g + 4kq + j.  Slot -> real channel: bk_fine_perm for the outputs of layers 0..5 (so that the
-//   k order of every dot product equals the coarse path's: the two paths agree bit for bit), identity for layer 6
+//   consume input SLOT 16g + 4kq + j.  Slot -> real channel: bk_slot_perm for the outputs of layers 0..5 (so that the
+//   k order of every dot product equals the round-1 kernel's: bit-identical results), identity for layer 6
 //   (the heads read natural channel order) and, for layer 0's input, the first 24 planes by the same permutation and
 //   planes 24..26 in k-step 2 of the second group (7 k-steps of 4 = 28 channels).
-void pack_trunk_fine(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
+void pack_trunk(const bk_trunk_weights& t, std::vector<float>& wfrag, std::vector<float>& bias) {
     wfrag.assign(BK_WFRAG_FLOATS + BK_WFRAG_PAD_FLOATS, 0.f);
     bias.assign(7 * 128, 0.f);
     size_t base = 0;
@@ -142,7 +110,7 @@ void pack_trunk_fine(const bk_trunk_weights& t, std::vector<float>& wfrag, std::
         const int K = l == 0 ? 5 : 3, cin = l == 0 ? 27 : 128, G = l == 0 ? 2 : 8, TAPS = K * K;
         std::vector<double> scale(128);
         for (int co = 0; co < 128; ++co) scale[co] = (double)t.bn_w[l][co] / std::sqrt((double)t.bn_var[l][co] + kBnEps);
-        auto out_ch = [&](int slot) { return l == 6 ? slot : bk_fine_perm(slot); };
+        auto out_ch = [&](int slot) { return l == 6 ? slot : bk_slot_perm(slot); };
         for (int sl = 0; sl < 128; ++sl) {
             const int co = out_ch(sl);
             bias[l * 128 + sl] = (float)(((double)t.conv_b[l][co] - (double)t.bn_mean[l][co]) * scale[co] + (double)t.bn_b[l][co]);
@@ -153,7 +121,7 @@ void pack_trunk_fine(const bk_trunk_weights& t, std::vector<float>& wfrag, std::
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 4; ++j) {
                             const int co = out_ch(16 * ct + (lane & 15)), kq = lane >> 4;
-                            int ci = bk_fine_perm(16 * g + 4 * kq + j);
+                            int ci = bk_slot_perm(16 * g + 4 * kq + j);
                             if (l == 0 && g == 1) ci = j < 2 ? ci : (j == 2 && kq < 3 ? 24 + kq : cin);
                             float v = 0.f;
                             if (ci < cin) v = (float)((double)t.conv_w[l][((size_t)co * cin + ci) * TAPS + tp] * scale[co]);
@@ -225,9 +193,6 @@ int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, doub
     int rc;
     if ((rc = upload(e, wfrag, &np.wfrag))) return rc;
     if ((rc = upload(e, bias, &np.bias))) return rc;
-    pack_trunk_fine(t, wfrag, bias);
-    if ((rc = upload(e, wfrag, &np.wfragF))) return rc;
-    if ((rc = upload(e, bias, &np.biasF))) return rc;
     if ((rc = upload(e, hw, &np.head_w))) return rc;
     if ((rc = upload(e, hb, &np.head_b))) return rc;
     std::vector<_Float16> w16;

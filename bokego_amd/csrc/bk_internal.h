@@ -4,12 +4,12 @@
 #include <stdint.h>
 
 // fragment-ordered weight buffer geometry (floats)
-// per layer: [tap][group of 8 cin][cout tile (4 x 32)][lane (64)][4]
-// layer 0: 25 taps x 4 groups x 1024   layers 1..6: 9 x 16 x 1024
-#define BK_L0_FLOATS (25 * 4 * 1024)
-#define BK_L3_FLOATS (9 * 16 * 1024)
+// per layer: [tap][group of 16 input slots][cout tile (8 x 16)][lane (64)][4]
+// layer 0: 25 taps x 2 groups x 2048   layers 1..6: 9 x 8 x 2048
+#define BK_L0_FLOATS (25 * 2 * 2048)
+#define BK_L3_FLOATS (9 * 8 * 2048)
 #define BK_WFRAG_FLOATS (BK_L0_FLOATS + 6 * BK_L3_FLOATS)
-#define BK_WFRAG_PAD_FLOATS 8192  // the weight prefetch runs up to 32 KiB past the last layer (fine path: 3 groups of 8 KiB)
+#define BK_WFRAG_PAD_FLOATS 8192  // the weight prefetch runs up to 32 KiB past the last layer (3 groups of 8 KiB)
 
 // f16x2 path: per layer [k16 step][cout tile (4)][piece hi/lo][lane (64)][8 halfs] = 4096 halfs per step
 #define BK16_L0_STEPS 52                      // 25 taps x 2 steps, zero-padded to a multiple of 4
@@ -25,12 +25,9 @@
 #define BK_FEATS_U8_ 1
 
 struct bk_net_params {
-    const float* wfrag;    // BK_WFRAG_FLOATS (+pad), BatchNorm folded
-    const float* bias;     // [7][128] folded conv bias
-    // fine-tile fp32 path (16x16x4 MFMA, 3-board workgroups): same sizes, other fragment order, channels of layers
-    // 0..5 kept in a permuted slot order (bk_fine_perm) that reproduces the coarse path's summation order bit for bit
-    const float* wfragF;
-    const float* biasF;    // [7][128] folded bias in slot order
+    const float* wfrag;    // BK_WFRAG_FLOATS (+pad), BatchNorm folded, fragment order of conv_layer (bk_kernels.hip);
+                           // channels of layers 0..5 in the slot order bk_slot_perm
+    const float* bias;     // [7][128] folded conv bias in slot order
     const float* head_w;   // [128]  (value net: BatchNorm2d(1) folded in)
     const float* head_b;   // [81]
     const float* lin1_wt;  // value: [81][64] = lin1.weight^T with BatchNorm1d folded
@@ -65,9 +62,10 @@ struct bk_eval_args {
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
-// fine path: real channel held by slot s of a layer-0..5 output record (a bit permutation inside each block of 16):
-// slot = 16g + 4kq + j is what MFMA k-step j of channel group g consumes from lane quad kq
-static inline int bk_fine_perm(int s) { return (s & ~15) | (((s >> 1) & 1) << 3) | (((s >> 2) & 1) << 2) | ((s & 1) << 1) | ((s >> 3) & 1); }
+// fp32 kernel: real channel held by slot s of a layer-0..5 output record (a bit permutation inside each block of 16):
+// slot = 16g + 4kq + j is what MFMA k-step j of channel group g consumes from lane quad kq; chosen so that the k order
+// of every dot product equals the round-1 kernel's (bit-identical results)
+static inline int bk_slot_perm(int s) { return (s & ~15) | (((s >> 1) & 1) << 3) | (((s >> 2) & 1) << 2) | ((s & 1) << 1) | ((s >> 3) & 1); }
 
 #define BK_POS_BYTES 192  // sizeof(bk_pos), include/bokego_go.h
 

@@ -3,25 +3,27 @@
 // Replaces, for a batch of positions, the reference's two forward passes
 //   PolicyNet.forward  (bokego/nnet.py:31-57)   + SOFT (nnet.py:16,273)
 //   ValueNet.forward   (bokego/nnet.py:73-113)
-// One workgroup (4 waves, one per SIMD) owns NB whole boards of ONE net and runs the whole
-// network on them without leaving the CU:
-//   * the NB x 81 x 128 fp32 activations live in LDS, position-major, in a "shared halo"
-//     layout (10-column rows: the zero column between two board rows is the right halo of
-//     one and the left halo of the next), so every 3x3 tap is a constant address offset and
-//     needs no bounds test; records are padded (528 B per position) so that the 16 lanes of a
-//     ds_read_b128 group hit 16 distinct LDS slots without any address swizzling;
-//   * each conv layer is an implicit GEMM  [32*MT positions] x [128 couts] x [taps*cin]  on the
-//     exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32, computed transposed (weights = A operand);
-//     the 4 waves form a 2x2 grid over [position tiles x cout tiles] (1x4 for NB = 1), every weight
-//     fragment comes straight from L2 into registers in a host-prepacked order (coalesced 1 KiB buffer
-//     loads, scalar offsets), and the conv loops contain no vector-ALU instruction besides the MFMAs;
-//   * the layer output stays in the accumulators until every wave has finished reading the
-//     layer input, then is written back IN PLACE (bias + ReLU fused, 16-byte stores): no ping-pong
-//     buffer, which is what lets 3 boards (147 KB) fit the 160 KB LDS;
-//   * the untied-bias 1x1 head, the 81-way softmax and the value MLP + tanh are wave-level
-//     reductions at the end of the same kernel.
-// HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2
-// resident).  BatchNorm (eval mode) is folded into the weights on the host in fp64.
+// One workgroup (8 waves, two per SIMD) owns NB whole boards of ONE net and runs the whole network on them without
+// leaving the CU:
+//   * the NB x 81 x 128 fp32 activations live in LDS, position-major, in a "shared halo" layout (10-column rows: the
+//     zero column between two board rows is the right halo of one and the left halo of the next), so every 3x3 tap is
+//     a constant address offset and needs no bounds test; records are padded (528 B per position) so that the 16 lanes
+//     of a ds_read_b128 group hit 16 distinct LDS slots without any address swizzling;
+//   * each conv layer is an implicit GEMM  [16-position tiles] x [128 couts] x [taps*cin]  on the exact-fp32 matrix
+//     instruction v_mfma_f32_16x16x4_f32 (bit-identical to an fmaf chain), computed transposed (weights = A operand);
+//     the board points are grouped into tiles by edge class so that taps which point off the board for a whole tile are
+//     skipped; every weight fragment comes straight from L2 into registers in a host-prepacked order (coalesced 1 KiB
+//     buffer loads, scalar offsets) and the conv loops contain no vector-ALU instruction besides the MFMAs;
+//   * the layer output stays in the accumulators until every wave has finished reading the layer input, then is written
+//     back IN PLACE (bias + ReLU fused, 16-byte stores): no ping-pong buffer, which is what lets 3 boards (147 KB) fit
+//     the 160 KB LDS;
+//   * the untied-bias 1x1 head, the 81-way softmax and the value MLP + tanh are wave-level reductions at the end of the
+//     same kernel.
+// HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2 resident).  BatchNorm (eval
+// mode) is folded into the weights on the host in fp64.
+// History: round 1 used 32-row tiles (v_mfma_f32_32x32x2_f32), an XOR-swizzled LDS layout and one wave per
+// SIMD; every later form was checked bit-identical to it on the GPU (tools/ab_bits.py), which is why the channel slots of
+// layers 0..5 are kept in the permuted order bk_slot_perm: it reproduces that kernel's summation order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -55,17 +57,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 // ---- LDS layouts -------------------------------------------------------------------------
-// No XOR swizzle: every address the conv loops use is (per-lane base) + (compile-time constant), so the loops
-// contain NO vector-ALU address arithmetic (on this chip the fp32 MFMA shares the vector ALU: every VALU
-// instruction between two MFMAs is lost MFMA time).  Bank conflicts are avoided by PADDING instead.
+// Every address the conv loops use is (per-lane base) + (compile-time constant), so the loops contain NO vector-ALU
+// address arithmetic (the fp32 MFMA shares the vector ALU: every VALU instruction between two MFMAs is lost MFMA
+// time).  Bank conflicts are avoided by PADDING, not by swizzling.
 //
 // 128-channel activations: one record per position = 512 B of data + 16 B pad (REC3 = 528); a board row is 10
 // records (column 0 = the zero halo shared by the end of one row and the start of the next) at a pitch of
 // RP3 = 10*528 - 16: the never-touched pad of a row's last record overlaps the first 16 B of the next row's
 // halo record.  The 16-byte slot of chunk c of (row R, column C) is (9R + C + c) mod 16, so the 16 lanes of a
 // ds_read_b128 lane group -- 16 consecutive board points in (y,x) order -- read 16 distinct slots.
-// NB == 3: boards are stacked without separator rows (R = 1 + 9b + y): the only rows that could read across a
-// board edge are the y=0 / y=8 rows, which sit alone in tiles 0 / 7 and skip those taps (RowMap below).
+// NB == 3: boards are stacked without separator rows (R = 1 + 9b + y): the only points that could read across a
+// board edge are the y=0 / y=8 points, which sit alone in their tiles and skip those taps (Tiles below).
 // NB < 3: a zero row after every board (R = 1 + 10b + y).
 constexpr int REC3 = 528, RP3 = 10 * REC3 - 16;
 // layer-0 input (27 channels in 32 slots = 128 B + 16 B pad, 5x5 taps): 11 records per row (columns 0,1 = halo),
@@ -75,30 +77,16 @@ constexpr int REC0 = 144, RP0 = 1808;
 
 template <int NB>
 struct Geo {
-    static constexpr int MT = (81 * NB + 31) / 32;  // 32-row MFMA tiles in the workgroup
     static constexpr int RB3 = NB == 3 ? 9 : 10, NROWS3 = 1 + NB * RB3;
     static constexpr int RB0 = NB == 3 ? 10 : 11, NROWS0 = 2 + NB * RB0;
     // + one record: the right-halo reads of the last row (column 10 resp. 11,12) land just behind it
     static constexpr int L3_BYTES = NROWS3 * RP3 + REC3;
     static constexpr int L0_BYTES = NROWS0 * RP0 + REC0;
     static_assert(L0_BYTES <= L3_BYTES, "the layer-0 input lives inside the activation region");
-        // the waves form a WM x WN grid over [position tiles x cout tiles]; a wave owns MTW position tiles x NT cout tiles
-    // Waves per workgroup.  One wave per SIMD (4) leaves the matrix pipe idle while that wave issues its loads and
-    // waits (65.06 cycles per MFMA, limit 64); with two waves per SIMD (8: each owns all its row group's position tiles
-    // and ONE 32-cout tile) the other wave's MFMA fills the slot: +1.1 % measured, bit-identical.  Measured and
-    // rejected: 8 waves as 4 position groups x 2 cout groups (+0.5 %), 16 waves as 4 x 4 (+0.4 %).
-#ifndef BK_FP32_NW2
-#define BK_FP32_NW2 8
-#endif
-#ifndef BK_FP32_NW3
-#define BK_FP32_NW3 8
-#endif
+        // 8 waves per workgroup = two per SIMD: while one wave issues its loads and waits, the other's MFMA keeps the matrix
+    // pipe busy (measured on the earlier 32-row-tile loop: 65.06 cycles per 64-cycle MFMA with one wave per SIMD, +1.1 % with two)
     static constexpr int NW = 8;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int WM = (MT % 2 == 0) ? 2 : 1;
-    static constexpr int WN = NW / WM;
-    static constexpr int NT = WN > 4 ? 1 : 4 / WN;      // (the 32-row form does not exist for 1 board x 8 waves: fine tiles only)
-    static constexpr int MTW = MT / WM;
     static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one shared record: never read)
     static constexpr int HS_FLOATS = NB * 96;
     static constexpr int LDS_BYTES = L3_BYTES + (DUMMY_FLOATS + HS_FLOATS) * 4;
@@ -106,269 +94,40 @@ struct Geo {
     static constexpr int addr3(int b, int y, int x) { return (1 + RB3 * b + y) * RP3 + (x + 1) * REC3; }  // bytes
     static constexpr int addr0(int b, int y, int x) { return (2 + RB0 * b + y) * RP0 + (x + 2) * REC0; }
 };
-// float slot of input channel c inside a layer-0 record.  Channels 0..23 in order (groups 0..2 of 8); the last
-// group holds only 24..26 (+ one zero), arranged so that TWO k-steps cover it: chunk (6+h)[j] = channel 24+2j+h.
-__device__ __forceinline__ int in_slot(int c) { return c < 24 ? c : (6 + ((c - 24) & 1)) * 4 + ((c - 24) >> 1); }
-
-// Flat GEMM row r of the workgroup -> board point.  NB == 3 orders the rows y-major so that tile 0
-// holds exactly the y=0 points of the three boards and tile 7 the y=8 points (27 + 5 padding rows
-// each; tiles 1..6 the 189 points with y in 1..7 + 3 padding rows): a tap with dy<0 reads only zero
-// halo for tile 0 and one with dy>0 only zero halo for tile 7, so those MFMAs are skipped.
-// constexpr: the epilogue uses it at compile time, the A-fragment addressing at run time.
-template <int NB>
-struct RowMap {
-    static constexpr bool valid(int r) {
-        return NB == 3 ? (r < 32 ? r < 27 : r < 224 ? r - 32 < 189 : r - 224 < 27) : r < 81 * NB;
-    }
-    static constexpr int b(int r) {
-        return !valid(r) ? 0 : NB == 3 ? (r < 32 ? r / 9 : r < 224 ? (r - 32) / 63 : (r - 224) / 9) : r / 81;
-    }
-    static constexpr int y(int r) {
-        return !valid(r) ? 4 : NB == 3 ? (r < 32 ? 0 : r < 224 ? 1 + ((r - 32) % 63) / 9 : 8) : (r % 81) / 9;
-    }
-    static constexpr int x(int r) {
-        return !valid(r) ? 0 : NB == 3 ? (r < 32 ? r % 9 : r < 224 ? ((r - 32) % 63) % 9 : (r - 224) % 9) : (r % 81) % 9;
-    }
-    static constexpr int addr3(int r) { return Geo<NB>::addr3(b(r), y(r), x(r)); }
-};
-
-// One conv layer for one wave: acc[mt][nt] (32 rows x 32 couts each) = sum over taps, cin.
-// wl: the layer's fragment-ordered weights [tap][group of 8 cin][cout tile (4)][lane][4].
-//
-// The K loop runs over taps (rolled); one tap = NBLK blocks of 4 channel groups (8 cin each), fully unrolled:
-//   A fragments  ds_read_b128 at (lane's tap pointer) + immediate (group*32 B); the tap pointers -- one per row
-//                tile -- advance by a wave-uniform delta once per tap: MTW vector adds per tap are the ONLY
-//                vector-ALU instructions besides the MFMAs;
-//   B fragments  buffer_load_dwordx4 with a scalar running offset (+4 KiB per group), lane offset constant:
-//                no vector address arithmetic, no 64-bit pointer carries;
-//   both software-pipelined through register ping-pong (A one group ahead, B one block ahead).
-// rowa[mt]: byte offset of this lane's row of tile mt at tap (0,0), chunk h (RowAddr below; computed once per kernel).
-// B0 / B1: the weight ping-pong buffers, owned by the kernel so that they live across layers: the loop's last block
-// always fetches "the next block", which is the first block of the NEXT layer (the layers are contiguous in memory).
-// PRELOADED: B0 already holds this layer's block 0 (fetched by the previous layer's last step, or ahead of the input
-// staging for layer 0), so the layer starts without waiting for an L2 round trip.  On return B1 (layer 0: 25 blocks)
-// resp. B0 (3x3 layers: 36 blocks) holds the next layer's block 0.
-template <int NB, bool FIRST, bool PRELOADED>
-__device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
-                                           f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], int lane, int wm, int wn,
-                                           const int (&rowa)[Geo<NB>::MTW], f32x4 (&B0)[4][Geo<NB>::NT],
-                                           f32x4 (&B1)[4][Geo<NB>::NT]) {
-    using G = Geo<NB>;
-    constexpr int MTW = G::MTW, NT = G::NT;
-    constexpr int KW = FIRST ? 5 : 3;
-    constexpr int TAPS = KW * KW;
-    constexpr int NBLK = FIRST ? 1 : 4;                 // blocks of 4 channel groups per tap
-    constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
-    const char* ap[MTW];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) ap[mt] = actb + rowa[mt];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-    // B fragments: block b (4 groups of 8 cin) of the layer is 16 KiB [group][cout tile][lane][4]; this wave
-    // reads cout tiles wn*NT .. wn*NT+NT-1: NT coalesced 1 KiB loads per group.
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + (wn * NT) * 256), 0, 0x7ffffff0, 0x00020000);
-    const int lane16 = lane * 16;
-    int boff = PRELOADED ? 16384 : 0;                   // scalar: byte offset of the block being fetched
-    auto load_b = [&](f32x4 (&B)[4][NT]) {
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                B[gg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16 + nt * 1024, boff + gg * 4096, 0));
-        boff += 16384;
-    };
-    auto read_a = [&](f32x4 (&A)[MTW], int imm) {
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + imm);
-    };
-
-    f32x4 A0[MTW], A1[MTW];
-
-    // One block = 4 groups.  Bc: its fragments, Bn receives the next block's.  Group parity alternates A0/A1.
-    // GB: the block's index inside its tap (compile time).  At the tap's last group the tap pointers move on
-    // (delta: wave-uniform) and the prefetch reads group 0 of the next tap.
-    // MLO..MHI: the row tiles of this wave that take part (zero-halo tap skipping, see RowMap)
-    auto do_block = [&](auto MLO, auto MHI, auto GBc, f32x4 (&Bc)[4][NT], f32x4 (&Bn)[4][NT], int delta) {
-        constexpr int mlo = decltype(MLO)::value, mhi = decltype(MHI)::value, gb = decltype(GBc)::value;
-        load_b(Bn);  // the layer's last block over-reads into the next layer / the pad: harmless
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            f32x4 (&Ac)[MTW] = (gg & 1) ? A1 : A0;
-            f32x4 (&An)[MTW] = (gg & 1) ? A0 : A1;
-            // layer 0: the last channel group holds 4 channels (24..26 + a zero) packed into k-steps 0 and 1
-            constexpr int JN = 4;
-            const int jn = (FIRST && gg == 3) ? 2 : JN;
-#pragma unroll
-            for (int mt = mlo; mt < mhi; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bc[gg][nt][0], Ac[mt][0], acc[mt][nt], 0, 0, 0);
-            if (gg == 3 && gb == NBLK - 1) {   // next group is group 0 of the next tap
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) ap[mt] += delta;
-                read_a(An, 0);
-            } else {
-                read_a(An, (gb * 4 + gg + 1) * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued right after the first MFMA round
-#pragma unroll
-            for (int j = 1; j < JN; ++j) {
-                if (j < jn) {
-#pragma unroll
-                    for (int mt = mlo; mt < mhi; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bc[gg][nt][j], Ac[mt][j], acc[mt][nt], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    using IM = std::integral_constant<int, MTW>;
-    // pointer delta from tap t to tap t+1 (0 after the layer's last tap: the final prefetch re-reads in place)
-    auto tap_delta = [&](int t) {
-        const int kx = t % KW;
-        return t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
-    };
-    // taps [t0, t1) with one tile range; the operand pipelines run across calls
-    auto run = [&](auto MLO, auto MHI, int t0, int t1) {
-        if constexpr (FIRST) {
-            // one block per tap: the B ping-pong alternates per tap, so two taps per iteration
-#pragma unroll 1
-            for (int t = t0; t + 1 < t1; t += 2) {
-                do_block(MLO, MHI, I0{}, B0, B1, tap_delta(t));
-                do_block(MLO, MHI, I0{}, B1, B0, tap_delta(t + 1));
-            }
-        } else {
-#pragma unroll 1
-            for (int t = t0; t < t1; ++t) {
-                const int d = tap_delta(t);
-                do_block(MLO, MHI, I0{}, B0, B1, d);
-                do_block(MLO, MHI, I1{}, B1, B0, d);
-                do_block(MLO, MHI, I2{}, B0, B1, d);
-                do_block(MLO, MHI, I3{}, B1, B0, d);
-            }
-        }
-    };
-
-    if constexpr (!PRELOADED) load_b(B0);
-    read_a(A0, 0);
-    constexpr int WMc = G::WM;
-    if constexpr (NB == 3 && !FIRST) {
-        // ky=0 is taps [0,3), ky=2 taps [6,9): the wave group holding tile 0 (y=0 points) skips it for dy<0, the one
-        // holding tile 7 (y=8 points) skips it for dy>0, wave groups in between (WM > 2) skip nothing
-        if (wm == 0) {
-            run(I1{}, IM{}, 0, 3);
-            run(I0{}, IM{}, 3, TAPS);
-        } else if (WMc == 2 || wm == WMc - 1) {
-            run(I0{}, IM{}, 0, 6);
-            run(I0{}, std::integral_constant<int, MTW - 1>{}, 6, TAPS);
-        } else {
-            run(I0{}, IM{}, 0, TAPS);
-        }
-    } else if constexpr (NB == 3 && FIRST) {
-        // ky=0,1 are taps [0,10), ky=3,4 taps [15,25); ranges of an even number of taps, the odd one out last
-        if (wm == 0) {
-            run(I1{}, IM{}, 0, 10);
-            run(I0{}, IM{}, 10, 24);
-            do_block(I0{}, IM{}, I0{}, B0, B1, 0);
-        } else if (WMc == 2 || wm == WMc - 1) {
-            run(I0{}, IM{}, 0, 16);
-            run(I0{}, std::integral_constant<int, MTW - 1>{}, 16, 24);
-            do_block(I0{}, std::integral_constant<int, MTW - 1>{}, I0{}, B0, B1, 0);
-        } else {
-            run(I0{}, IM{}, 0, 24);
-            do_block(I0{}, IM{}, I0{}, B0, B1, 0);
-        }
-    } else if constexpr (FIRST) {
-        run(I0{}, IM{}, 0, 24);
-        do_block(I0{}, IM{}, I0{}, B0, B1, 0);
-    } else {
-        run(I0{}, IM{}, 0, TAPS);
-    }
-}
-
-// bias + ReLU + in-place store of this wave's tiles.  The product is computed transposed (weights = A operand,
-// activations = B operand), so accumulator register 4q+e of (mt, nt) is cout 32*(wn*NT+nt) + 8q + 4h + e of THIS
-// lane's position (h = lane>>5): four consecutive couts per q = one 16-byte store at (the lane's record) +
-// (compile-time offset) -- no address arithmetic, 4 ds_write_b128 per tile, and the 16 lanes of a store group
-// write 16 distinct LDS slots.  Lanes whose row is padding (beyond 81*NB) store into a per-thread dummy record.
-template <int NB>
-struct Bias4 { f32x4 v[Geo<NB>::NT][4]; };
-// this lane's couts of a layer: bias[32*(wn*NT+nt) + 8q + 4h .. +3].  Issued BEFORE the layer's conv loop so that the
-// loads have long landed when the epilogue wants them.
-template <int NB>
-__device__ __forceinline__ void load_bias(Bias4<NB>& bv, const float* __restrict__ bias, int wn, int h) {
-#pragma unroll
-    for (int nt = 0; nt < Geo<NB>::NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv.v[nt][q] = *reinterpret_cast<const f32x4*>(bias + 32 * (wn * Geo<NB>::NT + nt) + 8 * q + 4 * h);
-}
-// storea[mt]: byte offset of this lane's record of tile mt + its cout block (RowAddr below); padding rows: the dummy record
-template <int NB>
-__device__ __forceinline__ void store_layer(char* actb, const f32x16 (&acc)[Geo<NB>::MTW][Geo<NB>::NT], const Bias4<NB>& bv,
-                                            const int (&storea)[Geo<NB>::MTW]) {
-    constexpr int MTW = Geo<NB>::MTW, NT = Geo<NB>::NT;
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        char* wp = actb + storea[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mt][nt][4 * q + e] + bv.v[nt][q][e], 0.f);
-                *reinterpret_cast<f32x4*>(wp + (32 * nt + 8 * q) * 4) = v;
-            }
-    }
-}
-
-// ================================ fine-tile path (2- and 3-board workgroups) ===========================================
-// Same workgroup (8 waves, two per SIMD), same LDS layout, same arithmetic -- but 16-row tiles
-// (v_mfma_f32_16x16x4_f32: 16 positions x 16 couts x 4 input channels, 32 cycles, the same FLOP rate as the 32x32x2
-// form).  With 16-row tiles the board points can be grouped by edge class, so more all-zero-halo taps are skipped:
+// ---- tiles ---------------------------------------------------------------------------------------------------------
+// 16-position tiles (v_mfma_f32_16x16x4_f32: 16 positions x 16 couts x 4 input channels, 32 cycles).  The board points
+// are grouped into tiles by edge class, and a tap skips an edge tile when it points off the board for every point of the
+// tile (wave-uniform branch):
 //   3 boards (243 points, 16 tiles): two position groups (wm = 0 / 1) x four cout groups; a wave = 8 tiles x 2 cout tiles
 //       [ x-edge | 5 interior | y-edge a | y-edge b ]    x-edge: 16 of the 21 points with x = 0 (wm 0) / x = 8 (wm 1), y in 1..7
 //                                                         y-edge: the 27 points with y = 0 / y = 8 (+ 5 padding rows)
 //                                                         interior: the rest (+ 3 padding rows at the very end)
-//       3x3 layers: 63 of 72 tile-taps (32-row form: 66 of 72 in 32-row units), layer 0: 170 of 200 (180): -4.6 % MFMA cycles
-//   2 boards (162 points, 11 tiles instead of six 32-row tiles = 12): one position group x eight cout groups; a wave = 11
-//       tiles x 1 cout tile   [ x=0 | x=8 | 7 interior | y=0 | y=8 ]   (14 / 14 / 98 + 4 left over / 16 / 16 points)
-//       3x3 layers: 87 of 99 tile-taps against 108 (12 x 9) in 16-row units for the 32-row form: -19 %
-// A tap skips an edge tile when it points off the board for every point of the tile (wave-uniform branch).
+//       3x3 layers: 63 of 72 tile-taps, layer 0: 170 of 200
+//   2 boards (162 points, 11 tiles): one position group x eight cout groups; a wave = 11 tiles x 1 cout tile
+//       [ x=0 | x=8 | 7 interior | y=0 | y=8 ]   (14 / 14 / 98 + 4 left over / 16 / 16 points); 3x3 layers: 87 of 99 tile-taps
+//   1 board (81 points, 6 tiles): no edge class fills a tile, every tile runs every tap
 // Channels: an MFMA k-step consumes 4 input channels, one per lane quad kq, and a lane's accumulator holds 4
-// consecutive output slots.  Outputs of layers 0..5 are kept in the slot order bk_fine_perm (bk_internal.h), which makes
-// the k order of every dot product equal to the 32-row form's (8-channel groups, pairs (j, j+4)): the two forms agree
-// BIT FOR BIT.  Layer 6 writes natural channel order for the heads.  The host packs weights and biases accordingly.
-// Scheduling of the fine path, measured on one box (leaf-evals/s at B = 4,096): hard sched_barrier fences between the
+// consecutive output slots.  Outputs of layers 0..5 are kept in the slot order bk_slot_perm (bk_internal.h), which makes
+// the k order of every dot product equal to the round-1 kernel's (8-channel groups, pairs (j, j+4)): bit-identical
+// results.  Layer 6 writes natural channel order for the heads.  The host packs weights and biases accordingly.
+// Scheduling of a channel group, measured on one box (leaf-evals/s at B = 4,096): hard sched_barrier fences between the
 // phases of a channel group 506.9 k; none (the compiler's own order) 510.4 k; none + the pattern hint below 511.9 k.
-#ifdef BK_FINE_FENCES
-#define FINE_SB __builtin_amdgcn_sched_barrier(0)
+#ifdef BK_PHASE_FENCES
+#define PHASE_FENCE __builtin_amdgcn_sched_barrier(0)
 #else
-#define FINE_SB do {} while (0)
+#define PHASE_FENCE do {} while (0)
 #endif
 // scheduling hint for one channel group: NMFMA matrix instructions with NREADS LDS reads and NLOADS weight loads dealt out
 // between them.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
 template <int NMFMA, int NREADS, int NLOADS, int... I>
-__device__ __forceinline__ void fine_sched_pattern(std::integer_sequence<int, I...>) {
+__device__ __forceinline__ void sched_pattern(std::integer_sequence<int, I...>) {
     ((__builtin_amdgcn_sched_group_barrier(0x008, NMFMA / NREADS + (I < NMFMA % NREADS ? 1 : 0), 0),
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0), __builtin_amdgcn_sched_group_barrier(0x020, I < NLOADS ? 1 : 0, 0)),
      ...);
 }
 template <int NB>
-struct Fine {
-    static_assert(NB >= 1 && NB <= 3, "fine tiles are laid out for 1-, 2- and 3-board workgroups");
+struct Tiles {
+    static_assert(NB >= 1 && NB <= 3, "tiles are laid out for 1-, 2- and 3-board workgroups");
     static constexpr int WM = NB == 3 ? 2 : 1;          // position groups
     static constexpr int WN = 8 / WM;                   // cout groups
     static constexpr int RT = NB == 3 ? 8 : NB == 2 ? 11 : 6;   // 16-position tiles per wave
@@ -380,10 +139,10 @@ struct Fine {
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
 };
-struct FineRow { int b, y, x; bool valid; };
+struct TileRow { int b, y, x; bool valid; };
 template <int NB>
-__device__ __forceinline__ FineRow fine_row(int wm, int rt, int p16) {
-    FineRow r{0, 4, 0, true};
+__device__ __forceinline__ TileRow tile_row(int wm, int rt, int p16) {
+    TileRow r{0, 4, 0, true};
     if constexpr (NB == 1) {
         const int i = rt * 16 + p16;
         if (i < 81) { r.y = i / 9; r.x = i % 9; } else r.valid = false;
@@ -415,25 +174,25 @@ __device__ __forceinline__ FineRow fine_row(int wm, int rt, int p16) {
     if (!r.valid) { r.b = 0; r.y = 4; r.x = 0; }   // padding rows compute from a valid address; stored to the dummy record
     return r;
 }
-// float slot of input plane c inside a layer-0 record: planes 0..23 by the inverse of bk_fine_perm, planes 24..26 are
+// float slot of input plane c inside a layer-0 record: planes 0..23 by the inverse of bk_slot_perm, planes 24..26 are
 // k-step 2 of the second channel group (slot 16 + 4kq + 2 for lane quad kq = c - 24)
-__device__ __forceinline__ int in_slot_fine(int c) {
+__device__ __forceinline__ int in_slot(int c) {
     return c < 24 ? (c & ~15) | ((c & 1) << 3) | (c & 4) | (((c >> 3) & 1) << 1) | ((c >> 1) & 1) : 16 + 4 * (c - 24) + 2;
 }
 
-// wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk_fine).
+// wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk).
 // rowa[rt]: byte offset of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4).
 // W0..W3: the weight ring, owned by the kernel so that it lives across layers: the last two groups of a layer fetch
 // "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
 // PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
 // after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
 template <int NB, bool FIRST, bool PRELOADED>
-__device__ __forceinline__ void conv_layer_fine(const char* actb, const float* __restrict__ wl,
-                                                f32x4 (&acc)[Fine<NB>::RT][Fine<NB>::CTW], int lane, int wm, int wn,
-                                                const int (&rowa)[Fine<NB>::RT], f32x4 (&W0)[Fine<NB>::CTW],
-                                                f32x4 (&W1)[Fine<NB>::CTW], f32x4 (&W2)[Fine<NB>::CTW],
-                                                f32x4 (&W3)[Fine<NB>::CTW]) {
-    using F = Fine<NB>;
+__device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
+                                                f32x4 (&acc)[Tiles<NB>::RT][Tiles<NB>::CTW], int lane, int wm, int wn,
+                                                const int (&rowa)[Tiles<NB>::RT], f32x4 (&W0)[Tiles<NB>::CTW],
+                                                f32x4 (&W1)[Tiles<NB>::CTW], f32x4 (&W2)[Tiles<NB>::CTW],
+                                                f32x4 (&W3)[Tiles<NB>::CTW]) {
+    using F = Tiles<NB>;
     constexpr int RT = F::RT, CTW = F::CTW;
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
@@ -482,7 +241,7 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         using IC = std::integral_constant<int, 0>;
         (void)IC{};
         load_w(Wn);
-        FINE_SB;
+        PHASE_FENCE;
         tiles(0, 1, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
         if (g == G - 1) {                               // next group is group 0 of the next tap
 #pragma unroll
@@ -491,28 +250,28 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
         } else {
             read_a(An, (g + 1) * 64);
         }
-        FINE_SB;
+        PHASE_FENCE;
         tiles(1, JN, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
-#ifndef BK_FINE_FENCES
+#ifndef BK_PHASE_FENCES
         // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs
-        fine_sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
+        sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
 #endif
-        FINE_SB;
+        PHASE_FENCE;
         if constexpr (F::X0 >= 0) {
             if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
-            FINE_SB;
+            PHASE_FENCE;
         }
         if constexpr (F::X1 >= 0) {
             if (!sx1) tiles(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
-            FINE_SB;
+            PHASE_FENCE;
         }
         if constexpr (F::Y0a >= 0) {
             if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
-            FINE_SB;
+            PHASE_FENCE;
         }
         if constexpr (F::Y1 >= 0) {
             if (!sy1) tiles(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
-            FINE_SB;
+            PHASE_FENCE;
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -571,13 +330,13 @@ __device__ __forceinline__ void conv_layer_fine(const char* actb, const float* _
 
 // bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 16*(CTW*wn + ct) + 4*kq .. +3 of its position
 template <int NB>
-__device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[Fine<NB>::RT][Fine<NB>::CTW],
-                                                 const f32x4 (&bv)[Fine<NB>::CTW], const int (&storea)[Fine<NB>::RT]) {
+__device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[Tiles<NB>::RT][Tiles<NB>::CTW],
+                                                 const f32x4 (&bv)[Tiles<NB>::CTW], const int (&storea)[Tiles<NB>::RT]) {
 #pragma unroll
-    for (int rt = 0; rt < Fine<NB>::RT; ++rt) {
+    for (int rt = 0; rt < Tiles<NB>::RT; ++rt) {
         char* wp = actb + storea[rt];
 #pragma unroll
-        for (int ct = 0; ct < Fine<NB>::CTW; ++ct) {
+        for (int ct = 0; ct < Tiles<NB>::CTW; ++ct) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][ct][e] + bv[ct][e], 0.f);
@@ -586,9 +345,9 @@ __device__ __forceinline__ void store_layer_fine(char* actb, const f32x4 (&acc)[
     }
 }
 template <int NB>
-__device__ __forceinline__ void load_bias_fine(f32x4 (&bv)[Fine<NB>::CTW], const float* __restrict__ biasF, int wn, int kq) {
+__device__ __forceinline__ void load_bias(f32x4 (&bv)[Tiles<NB>::CTW], const float* __restrict__ bias, int wn, int kq) {
 #pragma unroll
-    for (int ct = 0; ct < Fine<NB>::CTW; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(biasF + 16 * (Fine<NB>::CTW * wn + ct) + 4 * kq);
+    for (int ct = 0; ct < Tiles<NB>::CTW; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + 16 * (Tiles<NB>::CTW * wn + ct) + 4 * kq);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -605,10 +364,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // GATED: the redo of an f16x2 call on the device-pointer path (bk_eval_device*), enqueued right behind the f16x2
 // kernel on the same stream: a no-op unless that kernel raised the call's overflow tag.  A separate instantiation so
 // that profiles keep the real fp32 launches and these (normally empty) ones apart.
-// FINE: the 16-row-tile form of the conv layers (3-board workgroups only), see conv_layer_fine
-template <int NB, bool GATED, bool FINE>
+template <int NB, bool GATED>
 __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk_eval_args a) {
-    static_assert(FINE || NB > 1, "1-board workgroups exist in the fine-tile form only");
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
@@ -622,7 +379,6 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
 
     // block -> (net, task).  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
     // while both nets have tasks left bit 2 of the block id picks the net: each XCD's 4 MB L2 then
@@ -644,27 +400,17 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     const int nb = min(NB, (net ? a.B_value : a.B_policy) - b0);
 
     STAMP(0);
-    // weight ping-pong buffers (see conv_layer); layer 0's first block is requested before the input staging
-    constexpr int kWN = FINE ? 8 / (NB == 3 ? 2 : 1) : G::WN;   // cout groups of the wave grid (the fine form has its own)
-    const int wm = wave / kWN, wn = wave - wm * kWN;
-    f32x4 Bw0[4][G::NT], Bw1[4][G::NT];
-    constexpr int kCTW = NB == 3 ? 2 : 1;
-    f32x4 Wr0[kCTW], Wr1[kCTW], Wr2[kCTW], Wr3[kCTW];   // fine path: the weight ring (see conv_layer_fine)
-    if constexpr (FINE) {
-        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfragF + wn * kCTW * 256), 0, 0x7ffffff0, 0x00020000);
+    // wave grid and the weight ring (see conv_layer); layer 0's first two channel groups are requested before the staging
+    using F = Tiles<NB>;
+    const int wm = wave / F::WN, wn = wave - wm * F::WN;
+    f32x4 Wr0[F::CTW], Wr1[F::CTW], Wr2[F::CTW], Wr3[F::CTW];
+    {
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * F::CTW * 256), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-        for (int ct = 0; ct < kCTW; ++ct) {
+        for (int ct = 0; ct < F::CTW; ++ct) {
             Wr0[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 0, 0));
             Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
         }
-    }
-    if constexpr (!FINE) {
-        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + (wn * G::NT) * 256), 0, 0x7ffffff0, 0x00020000);
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-            for (int nt = 0; nt < G::NT; ++nt)
-                Bw0[gg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + nt * 1024, gg * 4096, 0));
     }
     // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
     // every thread fetches its <= ceil(NB*2187/256) elements first (all loads in flight: the loop used to pay one
@@ -697,78 +443,30 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
             const int e = tid + G::THREADS * k;
             if (e < n) {
                 const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + (FINE ? in_slot_fine(c) : in_slot(c)) * 4) = v[k];
+                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
             }
         }
     }
     __syncthreads();
 
     STAMP(1);
-    if constexpr (FINE) {
-        using F = Fine<NB>;
-        constexpr int RT = F::RT;
-        const int kq = lane >> 4;
-        f32x4 acc[RT][F::CTW];
-        // this lane's positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
-        // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's couts)
-        int rowa0[RT], rowa3[RT], storea[RT];
+    constexpr int RT = F::RT;
+    const int kq = lane >> 4;
+    f32x4 acc[RT][F::CTW];
+    // this lane's positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
+    // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's couts)
+    int rowa0[RT], rowa3[RT], storea[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const FineRow fr = fine_row<NB>(wm, rt, lane & 15);
-            rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
-            rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
-            storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
-        }
-        f32x4 bv[F::CTW];
-        load_bias_fine<NB>(bv, P.biasF, wn, kq);
-        conv_layer_fine<NB, true, true>(actb, P.wfragF, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
-        STAMP(2);
-        __syncthreads();  // everyone done reading the input planes
-        if constexpr (NB == 3) {
-            for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {   // clear the 38 halo records (see the 32-row form)
-                const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
-                const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
-                *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-            for (int i = tid; i < G::L3_BYTES / 16; i += G::THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-        STAMP(3);
-        store_layer_fine<NB>(actb, acc, bv, storea);
-        STAMP(4);
-        __syncthreads();
-        STAMP(5);
-#pragma unroll 1
-        for (int L = 1; L < 7; ++L) {
-            load_bias_fine<NB>(bv, P.biasF + L * 128, wn, kq);
-            conv_layer_fine<NB, false, true>(actb, P.wfragF + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
-            STAMP(2 + 4 * L);
-            __syncthreads();
-            STAMP(3 + 4 * L);
-            store_layer_fine<NB>(actb, acc, bv, storea);
-            STAMP(4 + 4 * L);
-            __syncthreads();
-            STAMP(5 + 4 * L);
-        }
-    } else {
-    f32x16 acc[G::MTW][G::NT];
-    // this lane's GEMM rows, decoded ONCE (the decode has divisions): LDS byte offsets for the A-fragment reads of
-    // layer 0 / layers 1..6 (tap (0,0), chunk h) and for the epilogue stores (record + this wave's cout block)
-    int rowa0[G::MTW], rowa3[G::MTW], storea[G::MTW];
-#pragma unroll
-    for (int mt = 0; mt < G::MTW; ++mt) {
-        const int r = (wm * G::MTW + mt) * 32 + (lane & 31);  // padding rows read a valid point and store to the dummy record
-        const int b = RowMap<NB>::b(r), y = RowMap<NB>::y(r), x = RowMap<NB>::x(r);
-        rowa0[mt] = G::addr0(b, y, x) - 2 * RP0 - 2 * REC0 + h * 16;
-        rowa3[mt] = G::addr3(b, y, x) - RP3 - REC3 + h * 16;
-        storea[mt] = RowMap<NB>::valid(r) ? G::addr3(b, y, x) + (wn * G::NT * 32 + 4 * h) * 4 : dummy_byte;
+    for (int rt = 0; rt < RT; ++rt) {
+        const TileRow fr = tile_row<NB>(wm, rt, lane & 15);
+        rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
+        rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
+        storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
     }
-    Bias4<NB> bv;
-    load_bias<NB>(bv, P.bias, wn, h);
-
-    // ---- layer 0: 5x5, 27(32) -> 128 ----
-    conv_layer<NB, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Bw0, Bw1);   // leaves layer 1's block 0 in Bw1
+    f32x4 bv[F::CTW];
+    load_bias<NB>(bv, P.bias, wn, kq);
+    // ---- layer 0: 5x5, 27 -> 128 ----
+    conv_layer<NB, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: the halo must read as zero
@@ -793,8 +491,8 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        load_bias<NB>(bv, P.bias + L * 128, wn, h);
-        conv_layer<NB, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Bw1, Bw0);   // roles swapped: in Bw1, out Bw1
+        load_bias<NB>(bv, P.bias + L * 128, wn, kq);
+        conv_layer<NB, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
@@ -802,8 +500,6 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
-    }
-
     }
 
     // ---- heads: wave w handles board w ----
@@ -859,13 +555,13 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     STAMP(30);
 }
 
-template <int NB, bool GATED, bool FINE>
+template <int NB, bool GATED>
 hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
     static bool attr_set_dev[64] = {false};  // the attribute is per device: one flag per device ordinal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     bool& attr_set = attr_set_dev[dev];
-    auto kern = bk_leaf_eval_kernel<NB, GATED, FINE>;
+    auto kern = bk_leaf_eval_kernel<NB, GATED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NB>::LDS_BYTES);
@@ -887,8 +583,7 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
 // the CUs) x (time of one round of nb-board workgroups, one per CU).  NB=1 workgroups are small enough to sit two per
 // CU but then share the pipes, so that buys nothing here.
 //   f16x2: measured round times 86 : 150 : 195 us
-//   fp32:  measured round times 0.33 : 0.55 : 0.754 ms (1 board: 32-row tiles, 4 waves; 2 and 3 boards: fine tiles,
-//          8 waves)
+//   fp32:  measured round times 0.33 : 0.55 : 0.754 ms
 long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision) {
     static const int t16[4] = {0, 44, 77, 100}, t32[4] = {0, 44, 73, 100};
     const long wgs = (B_policy + nb - 1) / nb + (B_value + nb - 1) / nb;
@@ -910,18 +605,16 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
 }
 
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {
-    // 2- and 3-board workgroups run the fine-tile form; BK_FP32_COARSE=1 selects the 32-row-tile form (same bits) for A/B runs
-    static const bool fine = getenv("BK_FP32_COARSE") == nullptr;
     if (a.gate) {
         switch (nb) {
-            case 1: return launch_nb<1, true, true>(a, stream);
-            case 2: return fine ? launch_nb<2, true, true>(a, stream) : launch_nb<2, true, false>(a, stream);
-            default: return fine ? launch_nb<3, true, true>(a, stream) : launch_nb<3, true, false>(a, stream);
+            case 1: return launch_nb<1, true>(a, stream);
+            case 2: return launch_nb<2, true>(a, stream);
+            default: return launch_nb<3, true>(a, stream);
         }
     }
     switch (nb) {
-        case 1: return launch_nb<1, false, true>(a, stream);
-        case 2: return fine ? launch_nb<2, false, true>(a, stream) : launch_nb<2, false, false>(a, stream);
-        default: return fine ? launch_nb<3, false, true>(a, stream) : launch_nb<3, false, false>(a, stream);
+        case 1: return launch_nb<1, false>(a, stream);
+        case 2: return launch_nb<2, false>(a, stream);
+        default: return launch_nb<3, false>(a, stream);
     }
 }

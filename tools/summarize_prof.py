@@ -19,8 +19,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL_OF = {"f32": "bk_leaf_eval_kernel<3, false, true>", "f16x2": "bk_leaf_eval_f16_kernel<3>"}
-TAIL_OF = {"f32": "bk_leaf_eval_kernel<2, false, true>"}
+KERNEL_OF = {"f32": "bk_leaf_eval_kernel<3, false>", "f16x2": "bk_leaf_eval_f16_kernel<3>"}
+TAIL_OF = {"f32": "bk_leaf_eval_kernel<2, false>"}
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
