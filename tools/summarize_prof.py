@@ -28,6 +28,12 @@ bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlin
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(stats)))
 B = bench["config"]["batch_per_gpu"]
+# per-precision extracts of the same csv (the rows of that precision's kernels only)
+for prec, pat in (("f32", "bk_leaf_eval_kernel<"), ("f16x2", "bk_leaf_eval_f16_kernel<")):
+    with open(os.path.join(dst, f"{tag}_kernel_stats_{prec}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(r for r in rows if pat in r["Name"])
 
 
 def bench_block(prec):
