@@ -10,8 +10,8 @@ The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the refe
 (torch fp32, bokego/nnet.py:31-57,73-113) -- timed over exactly --steps launches between barriers.  Beside it:
   sustained     the same launches looped for >= 2 s (DVFS / power settle), reported next to the --steps figure
   parity        measured IN THIS RUN on the timed engine through the timed entry point: max |dlogit| / |dprob| /
-                |dvalue| against the reference's recorded outputs for the 536 golden positions, plus a sample of
-                the timed workload against the CPU oracle
+                |dvalue| against the reference's recorded outputs for the 536 golden positions (the cpu_baseline leg
+                also checks a sample of the timed workload output against the CPU oracle it has loaded anyway)
   f16x2         the opt-in split-fp16 variant, same measurements, priced against the f16 MFMA peak
   roofline      bound = MFMA: SURVEY 8d's 266,838,272 algorithmic FLOP per leaf-eval over the dense MFMA peak of the
                 dtype the matrix unit executes; kernel time from HIP events on the launch stream
@@ -99,7 +99,7 @@ def usable_cores():
     return visible, quota, physical
 
 
-def cpu_baseline(pw, vw, x, budget_s=20.0):
+def cpu_baseline(pw, vw, x, gpu_logits=None, gpu_values=None, budget_s=20.0):
     """The reference's CPU path on this host, bounded to ~budget_s: (a) oracle/torch_ref.py -- the reference's own
     operators on torch CPU -- at B = 1 / 64 / 4096 with every usable physical core and with 1 thread (SURVEY 8d,
     BASELINE.md 4); (b) the plain-C port oracle/nnet_ref.c.  `value` = the fastest of them."""
@@ -140,6 +140,13 @@ def cpu_baseline(pw, vw, x, budget_s=20.0):
     Pc(x[:256]); Vc(x[:256])
     n = min(len(x), 2048)
     t0 = time.perf_counter(); Pc(x[:n]); Vc(x[:n]); c_all = n / (time.perf_counter() - t0)
+    # while the oracle is at hand: a sample of the TIMED GPU output against it (the workload has no recorded reference outputs)
+    check = None
+    if gpu_logits is not None:
+        sel = np.linspace(0, len(x) - 1, 48).astype(int)
+        check = {"positions": len(sel), "max_abs_dlogit_vs_oracle": float(np.abs(gpu_logits[sel] - Pc(x[sel])).max()),
+                 "max_abs_dvalue_vs_oracle": float(np.abs(gpu_values[sel] - Vc(x[sel])).max())}
+        assert check["max_abs_dlogit_vs_oracle"] < 2 * TOL["logit"] and check["max_abs_dvalue_vs_oracle"] < TOL["value"], check
     torch_best = max(v for k, v in res["all_cores"].items() if k.startswith("B"))
     best = max(torch_best, c_all)
     return {"value": best, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
@@ -147,7 +154,7 @@ def cpu_baseline(pw, vw, x, budget_s=20.0):
             "sample": f"same workload batch: torch CPU at B=1/64/{len(x)} with {cores} threads and B=1/64 with 1 thread, "
                       f"C port {n} positions with {cores} threads and 64 with 1; {time.perf_counter() - t_all:.1f}s of CPU work",
             "cpu_model": cpu_model(), "host_cpus_visible": visible, "cgroup_cpu_quota": quota, "physical_cores_visible": physical,
-            "torch_cpu_leaf_evals_per_s": res, "torch_threads_default": old,
+            "torch_cpu_leaf_evals_per_s": res, "torch_threads_default": old, "timed_output_vs_oracle_sample": check,
             "c_port_leaf_evals_per_s": {"threads": cores, "all_cores": c_all, "one_thread_B64": c_one}}
 
 
@@ -335,17 +342,7 @@ def main():
     per_rank = gather(args.batch * args.steps / head["dt_local"])
     assert eng.stats()["f16_device_overflow"] == 0
 
-    # a sample of the TIMED output against the CPU oracle (the workload has no recorded reference outputs)
-    wl_check = None
-    if rank == 0:
-        from oracle.oracle import OraclePolicy, OracleValue
-        sel = np.linspace(0, args.batch - 1, 48).astype(int)
-        lg = OraclePolicy(pw)(x_host[sel])
-        va = OracleValue(vw)(x_host[sel])
-        wl_check = {"positions": len(sel),
-                    "max_abs_dlogit_vs_oracle": float(np.abs(head["out"]["logits"].cpu().numpy()[sel] - lg).max()),
-                    "max_abs_dvalue_vs_oracle": float(np.abs(head["out"]["value"].cpu().numpy()[sel] - va).max())}
-        assert wl_check["max_abs_dlogit_vs_oracle"] < 2 * TOL["logit"] and wl_check["max_abs_dvalue_vs_oracle"] < TOL["value"], wl_check
+    head_logits, head_values = head["out"]["logits"].cpu().numpy(), head["out"]["value"].cpu().numpy()   # for the CPU leg's cross-check
 
     # ---- nested: the opt-in f16x2 variant, same engine, same measurements --------------------------------------------
     other = None
@@ -413,7 +410,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pw, vw, x_host)
+        cpu = cpu_baseline(pw, vw, x_host, head_logits, head_values)
         if sp is not None:
             sp["cpu_baseline"] = selfplay_cpu_baseline(cpu["cores"])
 
@@ -428,7 +425,8 @@ def main():
             "config": {"workload": f"configs[1]: batch={args.batch} 9x9 positions, PolicyNet logits+softmax and "
                                    "ValueNet, device-resident inputs/outputs",
                        "batch_per_gpu": args.batch, "weights": "policy_19 + value_synth (tests/golden)",
-                       "precision": args.precision, "parity": head_parity, "parity_workload_sample": wl_check,
+                       "precision": args.precision, "parity": head_parity,
+                       "parity_workload_sample": cpu["timed_output_vs_oracle_sample"] if cpu else None,
                        "sharding": f"positions x{world}, no data-path collective"},
             "sustained": head["sustained"],
             "roofline": roofline(args.precision, args.batch, head["kernel_ms"], head["sustained"], head["p10_p50_p90"]),
