@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 2
+BK_ABI_VERSION = 3
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -45,7 +45,8 @@ class Stats(ctypes.Structure):
                 ("kernel_ms_sum", ctypes.c_double), ("kernel_ms_count", ctypes.c_uint64),
                 ("last_kernel_ms", ctypes.c_double), ("f16_overflow_fallbacks", ctypes.c_uint64),
                 ("f16_device_overflow", ctypes.c_uint64), ("positions_encoded", ctypes.c_uint64),
-                ("split_launches", ctypes.c_uint64)]
+                ("split_launches", ctypes.c_uint64), ("coop_launches", ctypes.c_uint64),
+                ("coop_fallbacks", ctypes.c_uint64)]
 
 
 # every symbol include/bokego_amd.h declares: (restype, argtypes)
@@ -98,7 +99,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.bk_abi_version() != BK_ABI_VERSION:
+        if lib.bk_abi_version() != BK_ABI_VERSION and not os.environ.get("BK_LIB_ANY_ABI"):  # (tools/ab_bits.py: older builds)
             raise RuntimeError("libbokego_amd.so ABI version mismatch; rebuild")
         _lib = lib
     return _lib

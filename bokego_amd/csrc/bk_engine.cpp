@@ -71,6 +71,12 @@ struct bk_engine {
     // call's fp32 redo kernel), [1] = number of calls redone
     unsigned int* d_dev_flag = nullptr;
     unsigned int dev_seq = 0;
+    // cooperative small-batch launches (compute stream only: one exchange buffer): d_coop_sync[BK_COOP_MAX_TASKS] arrival
+    // counters; d_coop_flag[0] = tag of the last launch that gave up waiting, [1] = launches redone by the one-CU form
+    float* d_coop_xchg = nullptr;
+    unsigned int* d_coop_sync = nullptr;
+    unsigned int* d_coop_flag = nullptr;
+    unsigned int coop_seq = 0;
     unsigned long long* d_stamps = nullptr;  // diagnostic builds only
 };
 
@@ -306,6 +312,33 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         r.gate_tag = tag;
         return bk_launch_leaf_eval(r, nb, stream);
     };
+    // Small batches on the engine's own stream: S CUs per board (bk_kernels.hip, "cout-split form"), followed by the
+    // one-CU form gated on the cooperative launch having given up (stream-ordered, ~4 us when it did not).
+    if (const int slices = (precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && !getenv("BK_FORCE_NB"))
+                               ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0) {
+        if (++e->coop_seq == 0) e->coop_seq = 1;
+        a.coop_xchg = e->d_coop_xchg;
+        a.coop_sync = e->d_coop_sync;
+        a.coop_err = e->d_coop_flag;
+        a.coop_tag = e->coop_seq;
+        a.coop_fault = getenv("BK_COOP_FAULT") != nullptr;
+        HIP_TRY(e, bk_launch_leaf_eval_coop(a, slices, stream));
+        bk_eval_args r = a;
+        r.overflow = nullptr;
+        r.gate = e->d_coop_flag;
+        r.gate_tag = e->coop_seq;
+        HIP_TRY(e, bk_launch_leaf_eval(r, 1, stream));
+        e->st.coop_launches += 1;
+        if (timed) {
+            HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
+            e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
+            ++e->ev_pending;
+        }
+        e->st.evals += (uint64_t)B;
+        e->st.batches += 1;
+        if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
+        return BK_OK;
+    }
     // Launch plan: either one launch with the best single workgroup size, or k whole rounds of 3-board
     // workgroups (one per CU) followed by a tail launch whose workgroup size makes the partial last round
     // shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead of
@@ -447,6 +480,15 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, 2 * sizeof(unsigned int)));
     e->dev_allocs.push_back(e->d_dev_flag);
     TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
+    {
+        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (BK_COOP_MAX_TASKS + 2) * sizeof(unsigned int);
+        TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
+        e->dev_allocs.push_back(e->d_coop_xchg);
+        TRY_CREATE(hipMalloc((void**)&e->d_coop_sync, sb));
+        e->dev_allocs.push_back(e->d_coop_sync);
+        TRY_CREATE(hipMemset(e->d_coop_sync, 0, sb));
+        e->d_coop_flag = e->d_coop_sync + BK_COOP_MAX_TASKS;
+    }
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);
     e->ev_ring.resize(512);
@@ -691,6 +733,13 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
         HIP_TRY(e, hipDeviceSynchronize());  // the calls may sit on any caller stream
         HIP_TRY(e, hipMemcpy(f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
         e->st.f16_device_overflow = f[1];
+    }
+    if (e->d_coop_flag && e->coop_seq) {
+        unsigned int f[2] = {0, 0};
+        HIP_TRY(e, hipSetDevice(e->device));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipMemcpy(f, e->d_coop_flag, sizeof(f), hipMemcpyDeviceToHost));
+        e->st.coop_fallbacks = f[1];
     }
     *out = e->st;
     return BK_OK;

@@ -59,6 +59,14 @@ struct bk_eval_args {
     unsigned int* gate;
     unsigned int gate_tag;
     int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
+    // cooperative (cout-split) launches for small batches, bk_kernels.hip: exchange buffer [BK_COOP_MAX_TASKS][2][81][128]
+    // fp32, one arrival counter per task (zero between launches), and the flag a workgroup raises to coop_tag when its
+    // peers did not show up in time (the gated redo behind it then runs for real)
+    float* coop_xchg;
+    unsigned int* coop_sync;
+    unsigned int* coop_err;
+    unsigned int coop_tag;
+    int coop_fault;              // tests (env BK_COOP_FAULT): slice 1 of task 0 leaves before layer 3's meeting point
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
@@ -75,4 +83,7 @@ hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStre
 int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision);
 long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision);  // modelled time of one launch (arbitrary units)
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
+#define BK_COOP_MAX_TASKS 128
+int bk_coop_slices(int tasks, int n_cu);   // 0: not a cooperative case
+hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -35,6 +35,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef BK_EXP
 #define BK_EXP 0
@@ -138,6 +139,7 @@ struct Tiles {
     static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 6;
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
+    static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
 };
 struct TileRow { int b, y, x; bool valid; };
 template <int NB>
@@ -186,13 +188,13 @@ __device__ __forceinline__ int in_slot(int c) {
 // "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
 // PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
 // after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
-template <int NB, bool FIRST, bool PRELOADED>
+// F: the wave's tile set (Tiles<NB>, or CoopTiles<S, RH> of the cout-split small-batch kernel below).
+template <class F, bool FIRST, bool PRELOADED>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
-                                                f32x4 (&acc)[Tiles<NB>::RT][Tiles<NB>::CTW], int lane, int wm, int wn,
-                                                const int (&rowa)[Tiles<NB>::RT], f32x4 (&W0)[Tiles<NB>::CTW],
-                                                f32x4 (&W1)[Tiles<NB>::CTW], f32x4 (&W2)[Tiles<NB>::CTW],
-                                                f32x4 (&W3)[Tiles<NB>::CTW]) {
-    using F = Tiles<NB>;
+                                                f32x4 (&acc)[F::RT][F::CTW], int lane, int wm, int wn,
+                                                const int (&rowa)[F::RT], f32x4 (&W0)[F::CTW],
+                                                f32x4 (&W1)[F::CTW], f32x4 (&W2)[F::CTW],
+                                                f32x4 (&W3)[F::CTW]) {
     constexpr int RT = F::RT, CTW = F::CTW;
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
@@ -288,8 +290,8 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
         const bool lo_x = kx < KW / 2, hi_x = kx > KW / 2, lo_y = ky < KW / 2, hi_y = ky > KW / 2;
         // 3 boards: a wave's x-edge tile holds x = 0 (wm 0) or x = 8 (wm 1) points, its y-edge tiles y = 0 or y = 8
-        const bool sx0 = NB == 3 ? (wm == 0 ? lo_x : hi_x) : lo_x, sx1 = hi_x;
-        const bool sy0 = NB == 3 ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
+        const bool sx0 = F::WM_EDGES ? (wm == 0 ? lo_x : hi_x) : lo_x, sx1 = hi_x;
+        const bool sy0 = F::WM_EDGES ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
         if constexpr (FIRST) {
             if constexpr (decltype(PHc)::value == 0) {
                 do_group(I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
@@ -329,14 +331,14 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
 }
 
 // bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 16*(CTW*wn + ct) + 4*kq .. +3 of its position
-template <int NB>
-__device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[Tiles<NB>::RT][Tiles<NB>::CTW],
-                                                 const f32x4 (&bv)[Tiles<NB>::CTW], const int (&storea)[Tiles<NB>::RT]) {
+template <class F>
+__device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[F::RT][F::CTW],
+                                                 const f32x4 (&bv)[F::CTW], const int (&storea)[F::RT]) {
 #pragma unroll
-    for (int rt = 0; rt < Tiles<NB>::RT; ++rt) {
+    for (int rt = 0; rt < F::RT; ++rt) {
         char* wp = actb + storea[rt];
 #pragma unroll
-        for (int ct = 0; ct < Tiles<NB>::CTW; ++ct) {
+        for (int ct = 0; ct < F::CTW; ++ct) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][ct][e] + bv[ct][e], 0.f);
@@ -344,10 +346,10 @@ __device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[Tiles
         }
     }
 }
-template <int NB>
-__device__ __forceinline__ void load_bias(f32x4 (&bv)[Tiles<NB>::CTW], const float* __restrict__ bias, int wn, int kq) {
+template <class F>
+__device__ __forceinline__ void load_bias(f32x4 (&bv)[F::CTW], const float* __restrict__ bias, int wn, int kq) {
 #pragma unroll
-    for (int ct = 0; ct < Tiles<NB>::CTW; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + 16 * (Tiles<NB>::CTW * wn + ct) + 4 * kq);
+    for (int ct = 0; ct < F::CTW; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + 16 * (F::CTW * wn + ct) + 4 * kq);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -361,6 +363,97 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- stage NB boards' feature planes: NCHW global -> position-major LDS (layer-0 layout) ----
+// every thread fetches its <= ceil(NB*2187/THREADS) elements first (all loads in flight: the loop used to pay one
+// global-memory latency per element), then scatters them; non-temporal: the planes are read once and must not
+// evict weight lines from L2.  The caller's __syncthreads() follows.
+template <int NB, int THREADS>
+__device__ __forceinline__ void stage_input(const bk_eval_args& a, char* actb, int b0, int nb, int tid) {
+    using G = Geo<NB>;
+    constexpr int PER = (NB * 2187 + THREADS - 1) / THREADS;
+    const int n = nb * 2187;
+    float v[PER];
+    if (a.feats_dtype == BK_FEATS_F32_) {
+        const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + THREADS * k;
+            v[k] = e < n ? __builtin_nontemporal_load(X + e) : 0.f;
+        }
+    } else {
+        const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + THREADS * k;
+            v[k] = e < n ? (float)__builtin_nontemporal_load(X + e) : 0.f;
+        }
+    }
+    // zero the layer-0 region (halo!) while the loads fly
+    for (int i = tid; i < G::L0_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid + THREADS * k;
+        if (e < n) {
+            const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
+            *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
+        }
+    }
+}
+
+// ---- heads of one board (one wave): untied-bias 1x1 conv, then softmax (PolicyNet) or the value MLP + tanh ----
+// rec_base: LDS byte address of the board's point (0,0) record minus addr3(0,0,0) terms, i.e. G::addr3(b, y, x) is
+// formed by the caller's geometry; hv: 96 floats of LDS scratch; bg: the board's index in the batch.
+template <class G>
+__device__ __forceinline__ void run_heads(const bk_eval_args& a, const bk_net_params& P, const char* actb, float* hv,
+                                              int net, int lane, int board, int bg) {
+    float s[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = lane + 64 * k;
+        float d = 0.f;
+        if (q < 81) {
+            const int y = q / 9, x = q - 9 * y;
+            const f32x4* rec = reinterpret_cast<const f32x4*>(actb + G::addr3(board, y, x));
+            const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
+#pragma unroll 8
+            for (int cc = 0; cc < 32; ++cc) {
+                const f32x4 v = rec[cc];
+                const f32x4 w = hw[cc];
+                d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
+            }
+            d += P.head_b[q];
+        }
+        s[k] = d;
+    }
+    if (net == 0) {
+        // PolicyNet: logits = head; probs = softmax
+        const float m = wave_max(fmaxf(s[0], (lane + 64 < 81) ? s[1] : -INFINITY));
+        const float e0 = expf(s[0] - m);
+        const float e1 = (lane + 64 < 81) ? expf(s[1] - m) : 0.f;
+        const float inv = 1.f / wave_sum(e0 + e1);
+        if (a.logits) {
+            a.logits[(size_t)bg * 81 + lane] = s[0];
+            if (lane + 64 < 81) a.logits[(size_t)bg * 81 + lane + 64] = s[1];
+        }
+        if (a.probs) {
+            a.probs[(size_t)bg * 81 + lane] = e0 * inv;
+            if (lane + 64 < 81) a.probs[(size_t)bg * 81 + lane + 64] = e1 * inv;
+        }
+    } else {
+        // ValueNet: (BN2d folded) ReLU -> lin1 (BN1d folded) -> ReLU -> lin2 -> tanh
+        hv[lane] = fmaxf(s[0], 0.f);
+        if (lane + 64 < 81) hv[lane + 64] = fmaxf(s[1], 0.f);
+        __builtin_amdgcn_wave_barrier();
+        float z = P.lin1_b[lane];
+#pragma unroll 9
+        for (int q = 0; q < 81; ++q) z += P.lin1_wt[q * 64 + lane] * hv[q];
+        z = fmaxf(z, 0.f);
+        const float v = wave_sum(z * P.lin2_w[lane]) + P.lin2_b;
+        if (lane == 0 && a.values) a.values[bg] = tanhf(v);
+    }
+}
+
 // GATED: the redo of an f16x2 call on the device-pointer path (bk_eval_device*), enqueued right behind the f16x2
 // kernel on the same stream: a no-op unless that kernel raised the call's overflow tag.  A separate instantiation so
 // that profiles keep the real fp32 launches and these (normally empty) ones apart.
@@ -370,6 +463,9 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
         if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
+        // redo of a cooperative launch that gave up waiting: its counters are left anywhere
+        if (a.coop_sync && blockIdx.x == 0)
+            for (int i = threadIdx.x; i < BK_COOP_MAX_TASKS; i += G::THREADS) a.coop_sync[i] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
@@ -412,41 +508,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
             Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
         }
     }
-    // ---- stage the NB boards' feature planes: NCHW global -> position-major LDS ----
-    // every thread fetches its <= ceil(NB*2187/256) elements first (all loads in flight: the loop used to pay one
-    // global-memory latency per element), then scatters them; non-temporal: the planes are read once and must not
-    // evict weight lines from L2
-    {
-        constexpr int PER = (NB * 2187 + G::THREADS - 1) / G::THREADS;
-        const int n = nb * 2187;
-        float v[PER];
-        if (a.feats_dtype == BK_FEATS_F32_) {
-            const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int e = tid + G::THREADS * k;
-                v[k] = e < n ? __builtin_nontemporal_load(X + e) : 0.f;
-            }
-        } else {
-            const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int e = tid + G::THREADS * k;
-                v[k] = e < n ? (float)__builtin_nontemporal_load(X + e) : 0.f;
-            }
-        }
-        // zero the layer-0 region (halo!) while the loads fly
-        for (int i = tid; i < G::L0_BYTES / 16; i += G::THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = tid + G::THREADS * k;
-            if (e < n) {
-                const int b = e / 2187, ee = e - b * 2187, c = ee / 81, q = ee - c * 81, y = q / 9, x = q - 9 * y;
-                *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
-            }
-        }
-    }
+    stage_input<NB, G::THREADS>(a, actb, b0, nb, tid);
     __syncthreads();
 
     STAMP(1);
@@ -464,9 +526,9 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
     }
     f32x4 bv[F::CTW];
-    load_bias<NB>(bv, P.bias, wn, kq);
+    load_bias<F>(bv, P.bias, wn, kq);
     // ---- layer 0: 5x5, 27 -> 128 ----
-    conv_layer<NB, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
+    conv_layer<F, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: the halo must read as zero
@@ -483,7 +545,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     }
     __syncthreads();
     STAMP(3);
-    store_layer<NB>(actb, acc, bv, storea);
+    store_layer<F>(actb, acc, bv, storea);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -491,68 +553,196 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        load_bias<NB>(bv, P.bias + L * 128, wn, kq);
-        conv_layer<NB, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+        load_bias<F>(bv, P.bias + L * 128, wn, kq);
+        conv_layer<F, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
-        store_layer<NB>(actb, acc, bv, storea);
+        store_layer<F>(actb, acc, bv, storea);
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
     }
 
     // ---- heads: wave w handles board w ----
-    if (wave < nb) {
-        float s[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = lane + 64 * k;
-            float d = 0.f;
-            if (q < 81) {
-                const int y = q / 9, x = q - 9 * y;
-                const f32x4* rec = reinterpret_cast<const f32x4*>(actb + G::addr3(wave, y, x));
-                const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
-#pragma unroll 8
-                for (int cc = 0; cc < 32; ++cc) {
-                    const f32x4 v = rec[cc];
-                    const f32x4 w = hw[cc];
-                    d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
-                }
-                d += P.head_b[q];
-            }
-            s[k] = d;
-        }
-        const int bg = b0 + wave;
-        if (net == 0) {
-            // PolicyNet: logits = head; probs = softmax
-            const float m = wave_max(fmaxf(s[0], (lane + 64 < 81) ? s[1] : -INFINITY));
-            const float e0 = expf(s[0] - m);
-            const float e1 = (lane + 64 < 81) ? expf(s[1] - m) : 0.f;
-            const float inv = 1.f / wave_sum(e0 + e1);
-            if (a.logits) {
-                a.logits[(size_t)bg * 81 + lane] = s[0];
-                if (lane + 64 < 81) a.logits[(size_t)bg * 81 + lane + 64] = s[1];
-            }
-            if (a.probs) {
-                a.probs[(size_t)bg * 81 + lane] = e0 * inv;
-                if (lane + 64 < 81) a.probs[(size_t)bg * 81 + lane + 64] = e1 * inv;
-            }
-        } else {
-            // ValueNet: (BN2d folded) ReLU -> lin1 (BN1d folded) -> ReLU -> lin2 -> tanh
-            float* hv = hs + wave * 96;
-            hv[lane] = fmaxf(s[0], 0.f);
-            if (lane + 64 < 81) hv[lane + 64] = fmaxf(s[1], 0.f);
-            __builtin_amdgcn_wave_barrier();
-            float z = P.lin1_b[lane];
-#pragma unroll 9
-            for (int q = 0; q < 81; ++q) z += P.lin1_wt[q * 64 + lane] * hv[q];
-            z = fmaxf(z, 0.f);
-            const float v = wave_sum(z * P.lin2_w[lane]) + P.lin2_b;
-            if (lane == 0 && a.values) a.values[bg] = tanhf(v);
-        }
-    }
+    if (wave < nb) run_heads<G>(a, P, actb, hs + wave * 96, net, lane, wave, b0 + wave);
     STAMP(30);
+}
+
+// ---- the cout-split form for small batches -------------------------------------------------------------------------------
+// With fewer one-board tasks than CUs the form above leaves most of the chip idle and a batch takes the 0.33 ms one CU
+// needs for a whole network (a 1600-rollout genmove is ~10 such batches of 40..80 boards).  Here S workgroups on S CUs
+// share ONE board of one net: each computes 128/S output channels of every layer for all 81 points, publishes its slice
+// in global memory (L2), meets its S-1 peers at a counter and fetches their slices into its own LDS copy of the
+// activations.  Every dot product runs in the same k order on the same instruction as in the forms above, so the
+// results are bit-identical to theirs.
+//   * waves: (8/S cout tiles) x (RH groups of 6/RH position tiles); weights, biases, LDS layout: as for 1 board;
+//   * exchange buffer: [task][layer parity][point][128 slots] fp32 -- a workgroup that is one layer ahead writes the other
+//     parity, and cannot get two ahead before every peer has arrived at the counter in between;
+//   * the meeting point: one thread adds 1 to the task's counter (release, agent scope: peers may sit on another XCD
+//     with another L2) and polls until all S arrivals of this layer are in; the counter runs 0 .. 7S and the slice that
+//     computes the heads puts it back to 0.  blocks x + 8(S j + s) are the S slices of task 8j + x: with the round-robin
+//     dealing of blocks to XCDs they share an L2 and follow each other in that XCD's dispatch order (a partly resident
+//     group waits only for blocks that are dispatched before any later group's).  The poll is BOUNDED: after ~20 ms
+//     without the peers (the card shared with something that holds CUs for that long) the workgroup raises
+//     coop_err = coop_tag and runs on to the end, and the gated launch the engine enqueues behind every cooperative one
+//     recomputes the batch with the one-CU form and clears the counters.
+template <int S, int RH>
+struct CoopTiles {
+    static_assert((S == 2 || S == 4 || S == 8) && 6 % RH == 0, "slices of 64 / 32 / 16 output channels");
+    static constexpr int RT = 6 / RH, CTW = 1;
+    static constexpr int A0 = 0, A1 = RT, X0 = -1, X1 = -1, Y0a = -1, Y0b = -1, Y1 = -1;
+    static constexpr bool WM_EDGES = false;
+    static constexpr int CT = 8 / S;                    // cout tiles per workgroup
+    static constexpr int NW = CT * RH, THREADS = 64 * NW;
+    static constexpr int XCHG_FLOATS = 2 * 81 * 128;    // per task: two layer parities
+};
+constexpr int COOP_SPIN_LIMIT = 1 << 15;
+
+template <int S, int RH>
+__global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop_kernel(const bk_eval_args a) {
+    using G = Geo<1>;
+    using F = CoopTiles<S, RH>;
+    constexpr int THREADS = F::THREADS, RT = F::RT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* actb = smem;
+    const int dummy_byte = G::L3_BYTES;
+    float* hs = reinterpret_cast<float*>(smem + G::L3_BYTES) + G::DUMMY_FLOATS;
+    __shared__ int dead;                                // a poll of this workgroup ran out: stop waiting
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int slice = (bid >> 3) % S, task = ((bid >> 3) / S) * 8 + (bid & 7);
+    if (task >= a.tasks_p + a.tasks_v) return;          // the grid is padded to whole groups of 8 tasks
+    const int net = task >= a.tasks_p;
+    const bk_net_params& P = a.net[net];
+    const int bg = net ? a.off_v + task - a.tasks_p : a.off_p + task;
+    float* xb = a.coop_xchg + (size_t)task * F::XCHG_FLOATS;
+    unsigned int* cnt = a.coop_sync + task;
+
+    const int wc = wave / RH, rh = wave - wc * RH;
+    const int wn = slice * F::CT + wc;                  // this wave's cout tile (of 8)
+    f32x4 Wr0[1], Wr1[1], Wr2[1], Wr3[1];
+    {
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
+        Wr0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 0, 0));
+        Wr1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 8192, 0));
+    }
+    if (tid == 0) dead = 0;
+    stage_input<1, THREADS>(a, actb, bg, 1, tid);
+    __syncthreads();
+
+    const int kq = lane >> 4;
+    f32x4 acc[RT][1];
+    int rowa0[RT], rowa3[RT], storea[RT], xoff[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const TileRow fr = tile_row<1>(0, rh * RT + rt, lane & 15);
+        rowa0[rt] = G::addr0(0, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
+        rowa3[rt] = G::addr3(0, fr.y, fr.x) - RP3 - REC3 + kq * 16;
+        storea[rt] = fr.valid ? G::addr3(0, fr.y, fr.x) + (16 * wn + 4 * kq) * 4 : dummy_byte;
+        xoff[rt] = fr.valid ? (9 * fr.y + fr.x) * 128 + 16 * wn + 4 * kq : -1;
+    }
+    f32x4 bv[1];
+
+    // own slice: LDS + exchange buffer; then meet the peers and fetch theirs.  After the last layer only slice 0 goes on.
+    // Coherence without cache-wide fences (a buffer_wbl2 / buffer_inv per wave and layer cost more than the convolutions
+    // once 30 groups shared an L2): the slices are written and read with device-scope (sc1) accesses, a wave waits for
+    // its stores to be acknowledged before the workgroup barrier, and the counter is a device-scope atomic.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, F::XCHG_FLOATS * 4, 0x00020000);
+    constexpr int SC1 = 16;                             // cache-policy bit of the buffer builtins on gfx94x/95x
+    auto exchange = [&](int L) -> bool {
+        const int par = (L & 1) * (81 * 128 * 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][0][e] + bv[0][e], 0.f);
+            *reinterpret_cast<f32x4*>(actb + storea[rt]) = v;
+            if (xoff[rt] >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xr, xoff[rt] * 4, par, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool last = L == 6;
+        if (a.coop_fault && L == 3 && task == 0 && slice == 1) return false;   // test hook: a peer that never arrives
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(last && slice != 0) && !dead) {
+                const unsigned int target = (unsigned int)S * (L + 1);
+                int spins = 0;
+#pragma unroll 1
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > COOP_SPIN_LIMIT) {
+                        atomicMax(a.coop_err, a.coop_tag);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        if (last && slice != 0) return false;           // uniform over the workgroup
+        __syncthreads();
+        // the peers' slices: 81 points x (32 - 32/S) 16-byte chunks
+        constexpr int OWN = 32 / S, PER = (81 * 32 + THREADS - 1) / THREADS;
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + THREADS * k, c = i & 31;
+            if (i < 81 * 32 && (c / OWN) != slice) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, i * 16, par, SC1));
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + THREADS * k, q = i >> 5, c = i & 31;
+            if (i < 81 * 32 && (c / OWN) != slice) {
+                const int y = q / 9, x = q - 9 * y;
+                *reinterpret_cast<f32x4*>(actb + G::addr3(0, y, x) + c * 16) = v[k];
+            }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    // ---- layer 0: 5x5, 27 -> 128 ----
+    load_bias<F>(bv, P.bias, wn, kq);
+    conv_layer<F, true, true>(actb, P.wfrag, acc, lane, 0, wn, rowa0, Wr0, Wr1, Wr2, Wr3);
+    __syncthreads();
+    for (int i = tid; i < G::L3_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    exchange(0);
+    // ---- layers 1..6: 3x3, 128 -> 128 ----
+#pragma unroll 1
+    for (int L = 1; L < 7; ++L) {
+        load_bias<F>(bv, P.bias + L * 128, wn, kq);
+        conv_layer<F, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, 0, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+        __syncthreads();
+        if (!exchange(L)) return;
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (wave == 0) run_heads<G>(a, P, actb, hs, net, lane, 0, bg);
+}
+
+template <int S, int RH>
+hipError_t launch_coop(const bk_eval_args& a, hipStream_t stream) {
+    static bool attr_set_dev[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    auto kern = bk_leaf_eval_coop_kernel<S, RH>;
+    if (!attr_set_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set_dev[dev] = true;
+    }
+    bk_eval_args args = a;
+    args.tasks_p = a.B_policy - a.off_p;
+    args.tasks_v = a.B_value - a.off_v;
+    const int tasks = args.tasks_p + args.tasks_v;
+    if (tasks == 0) return hipSuccess;
+    const int grid = (tasks + 7) / 8 * 8 * S;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CoopTiles<S, RH>::THREADS), Geo<1>::LDS_BYTES, stream, args);
+    return hipGetLastError();
 }
 
 template <int NB, bool GATED>
@@ -602,6 +792,30 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;
+}
+
+// slices per board of the cooperative form for `tasks` one-board tasks on n_cu CUs; 0: use the ordinary forms
+int bk_coop_slices(int tasks, int n_cu) {
+    if (tasks <= 0 || tasks > BK_COOP_MAX_TASKS) return 0;
+    if (const char* f = getenv("BK_COOP")) {
+        const int v = atoi(f);
+        if (v == 0) return 0;
+        if ((v == 2 || v == 4 || v == 8) && (tasks + 7) / 8 * 8 * v <= 2 * n_cu) return v;
+    }
+    // measured (tools/coop_probe.py, us per call incl. the gated launch; one CU per board: 330):
+    //   8 CUs per board: 92 (2 tasks) .. 110 (17) .. 114 (32);  4: 111 (2) .. 117 (63);  2: 188 (2) .. 197 (128)
+    if (tasks * 16 <= n_cu) return 8;
+    if (tasks * 4 <= n_cu) return 4;
+    if (tasks * 2 <= n_cu) return 2;
+    return 0;
+}
+
+hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream) {
+    switch (slices) {
+        case 8: return launch_coop<8, 6>(a, stream);
+        case 4: return launch_coop<4, 2>(a, stream);
+        default: return launch_coop<2, 2>(a, stream);
+    }
 }
 
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream) {

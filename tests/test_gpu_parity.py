@@ -414,9 +414,9 @@ def test_sweep_worst_cases_vs_reference(precision, wset):
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
 def test_every_workgroup_size_gives_the_same_bits(precision, monkeypatch):
-    """1-, 2- and 3-board workgroups (BK_FORCE_NB) are three different code paths -- for fp32 the 1-board form uses
-    32-row MFMA tiles and 4 waves, the 2- and 3-board forms 16-row tiles with edge-class tap skipping, permuted channel
-    slots and 8 waves -- and must agree bit for bit on every output, for ragged batch sizes and policy prefixes."""
+    """1-, 2- and 3-board workgroups (BK_FORCE_NB) are three different code paths -- different tile sets, edge-class tap
+    skipping for 2 and 3 boards, different wave grids -- and must agree bit for bit on every output, for ragged batch
+    sizes and policy prefixes."""
     from bokego_amd.engine import LeafEngine
     from bokego_amd.workload import make_batch
     x = make_batch(700, seed_base=123_000, dtype=np.uint8)
@@ -433,3 +433,96 @@ def test_every_workgroup_size_gives_the_same_bits(precision, monkeypatch):
         for a, b in zip(outs[1], outs[nb]):
             for k in b:
                 assert np.array_equal(a[k], b[k]), (nb, k)
+
+
+def _small_batches(eng, x):
+    return [eng.eval(x[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
+            for B, npol in ((1, 1), (1, 0), (2, 2), (5, 3), (9, 9), (16, 1), (31, 0), (40, 1), (62, 1), (63, 30), (64, 64), (100, 28), (128, 0))]
+
+
+def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
+    """Small fp32 batches on the engine's stream run with 8 / 4 / 2 CUs per board (cout-split cooperative kernel,
+    bk_stats().coop_launches): every output bit-identical to the one-CU-per-board form (BK_COOP=0), for each slice
+    count forced over the whole range as well as for the engine's own choice, with no fallback taken."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(128, seed_base=321_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=256)
+    monkeypatch.setenv("BK_COOP", "0")
+    ref = _small_batches(eng, x)
+    assert eng.stats()["coop_launches"] == 0
+    for mode in (None, "2", "4", "8"):
+        if mode is None:
+            monkeypatch.delenv("BK_COOP")
+        else:
+            monkeypatch.setenv("BK_COOP", mode)
+        c0 = eng.stats()["coop_launches"]
+        got = _small_batches(eng, x)
+        assert eng.stats()["coop_launches"] - c0 >= (13 if mode in (None, "2") else 8), mode
+        for a, b in zip(ref, got):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (mode, k, a[k].shape)
+    assert eng.stats()["coop_fallbacks"] == 0
+    # f32 feature planes through the same path; and the goldens' empty board
+    xf = x[:40].astype(np.float32)
+    monkeypatch.delenv("BK_COOP")
+    a = eng.eval(xf, logits=True, probs=True, value=True)
+    monkeypatch.setenv("BK_COOP", "0")
+    b = eng.eval(xf, logits=True, probs=True, value=True)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    eng.close()
+
+
+def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
+    """The meeting points of the cooperative kernel hold under repetition and with a second engine's large launches
+    competing for the CUs from another stream: 300 small evaluations of varying size, every one equal to the first
+    answer for its size."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(2048, seed_base=99_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng, other = LeafEngine(pw, vw, max_batch=256), LeafEngine(pw, vw, max_batch=2048)
+    sizes = (1, 7, 33, 62, 90)
+    first = {B: eng.eval(x[:B], probs=True, value=True, n_policy=min(B, 3)) for B in sizes}
+    pending = []
+    for i in range(300):
+        if i % 10 == 0:                       # a 2048-board launch of the other engine in flight (its own stream)
+            pending.append(other.submit(x, probs=True, value=True))
+        B = sizes[i % len(sizes)]
+        got = eng.eval(x[:B], probs=True, value=True, n_policy=min(B, 3))
+        for k in got:
+            assert np.array_equal(got[k], first[B][k]), (i, B, k)
+        if len(pending) > 2:
+            other.wait(pending.pop(0))
+    for t in pending:
+        other.wait(t)
+    st = eng.stats()
+    assert st["coop_launches"] >= 300
+    eng.close()
+    other.close()
+
+
+def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
+    """BK_COOP_FAULT makes one slice of one board leave before a meeting point: its peers give up after the bounded
+    wait, the gated one-CU launch behind the cooperative one recomputes the batch (bk_stats().coop_fallbacks), the
+    outputs are the usual bits, and the next cooperative launch finds its counters clean."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(48, seed_base=5_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=64)
+    monkeypatch.setenv("BK_COOP", "0")
+    ref = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
+    monkeypatch.delenv("BK_COOP")
+    monkeypatch.setenv("BK_COOP_FAULT", "1")
+    bad = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
+    monkeypatch.delenv("BK_COOP_FAULT")
+    st = eng.stats()
+    assert st["coop_fallbacks"] == 1 and st["coop_launches"] == 1
+    good = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
+    st = eng.stats()
+    assert st["coop_fallbacks"] == 1 and st["coop_launches"] == 2
+    for k in ref:
+        assert np.array_equal(ref[k], bad[k]) and np.array_equal(ref[k], good[k]), k
+    eng.close()

@@ -1,0 +1,50 @@
+"""Where a 1600-rollout genmove spends its time on the native tree: evaluator calls, their batch sizes and latency.
+    python tools/genmove_probe.py [moves] [precision]"""
+import os
+import sys
+import time
+from collections import Counter
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402,F401
+
+from bokego_amd import mcts, nnet  # noqa: E402
+from bokego_amd.bkw import load_bkw  # noqa: E402
+from bokego_amd.mcts_native import NativeMCTS  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+moves = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+precision = sys.argv[2] if len(sys.argv) > 2 else None
+pi, val = nnet.HipPolicyNet(precision=precision), nnet.HipValueNet(precision=precision)
+pi.load_state_dict(load_bkw(os.path.join(G, "policy_19.bkw")))
+val.load_state_dict(load_bkw(os.path.join(G, "value_synth.bkw")))
+tree = NativeMCTS(mcts.Go_MCTS(), pi, val)
+ev = tree.evaluator
+sizes, lat = Counter(), []
+orig = ev.__class__.__call__
+
+
+def timed(self, feats, npol):
+    t = time.perf_counter()
+    r = orig(self, feats, npol)
+    lat.append(time.perf_counter() - t)
+    sizes[(len(feats), int(npol))] += 1
+    return r
+
+
+ev.__class__.__call__ = timed
+tree.rollout(200); tree.choose()       # warm
+sizes.clear(); lat.clear()
+per_move = []
+for _ in range(moves):
+    t = time.perf_counter()
+    tree.rollout(1600)
+    tree.choose()
+    per_move.append(time.perf_counter() - t)
+    if tree.root._terminal:
+        break
+n = len(per_move)
+print(f"moves {n}  ms/move mean {1e3 * sum(per_move) / n:.3f}  min {1e3 * min(per_move):.3f}  max {1e3 * max(per_move):.3f}")
+print(f"evaluator calls {len(lat)} = {len(lat) / n:.1f} per move; in-evaluator time {1e3 * sum(lat) / n:.3f} ms/move; "
+      f"per call median {1e6 * sorted(lat)[len(lat) // 2]:.0f} us  p10 {1e6 * sorted(lat)[len(lat) // 10]:.0f} us")
+print("batch (boards, policy rows) -> calls:", dict(sizes.most_common(12)))
