@@ -41,7 +41,7 @@ def test_struct_layout_matches_header():
     # 7*6 + 2 pointers in the trunk, +12 in the value head (include/bokego_amd.h)
     assert ctypes.sizeof(_lib.TrunkWeights) == 44 * 8
     assert ctypes.sizeof(_lib.ValueWeights) == 56 * 8
-    assert ctypes.sizeof(_lib.Stats) == 80
+    assert ctypes.sizeof(_lib.Stats) == 96
 
 
 def test_create_argument_errors(lib):
