@@ -19,6 +19,9 @@ The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the refe
                 oracle/nnet_ref.c, the plain-C port) on a bounded sample of the same workload
   selfplay      secondary, outside the timed region: BASELINE configs[3] (512 self-play games sharded over the
                 ranks + the end-of-generation all-reduce), per precision, with a CPU baseline at N=1.
+  small_batch_latency  secondary: kernel time of the batches a single-tree genmove issues (configs[2]/[4]: 1 policy row +
+                ~60 value rows) and of a single position (configs[0]), one CU per board against the cooperative
+                cout-split launch (4 resp. 8 CUs per board; bit-identical outputs)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -386,6 +389,35 @@ def main():
         e2e_u8 = pipelined(lambda: eng.submit(x_u8, logits=False, probs=True, value=True))
         e2e_pos = pipelined(lambda: eng.submit_positions(x_recs, logits=False, probs=True, value=True))
 
+    # The genmove regime (BASELINE configs[2]/[4]: one tree, 1600 rollouts/move): expansion batches of one policy row +
+    # 40..70 value rows, latency-bound.  Kernel time of such a batch with one CU per board against the cooperative
+    # cout-split launch (4 CUs per board here; 8 for the single position of configs[0]).
+    small = None
+    if rank == 0 and args.precision == "f32":
+        def kernel_us(B, reps=20):
+            xs = x_u8[:B]
+            for _ in range(3):
+                eng.eval(xs, probs=True, value=True, n_policy=1)
+            eng.set_profiling(True)
+            s0 = eng.stats()
+            for _ in range(reps):
+                eng.eval(xs, probs=True, value=True, n_policy=1)
+            s1 = eng.stats()
+            eng.set_profiling(False)
+            return (1e3 * (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / (s1["kernel_ms_count"] - s0["kernel_ms_count"]),
+                    s1["coop_launches"] - s0["coop_launches"], s1["coop_fallbacks"] - s0["coop_fallbacks"])
+        small = {"what": "kernel time (HIP events) of one host-path evaluation of B boards + 1 policy row, us"}
+        saved = os.environ.get("BK_COOP")
+        for B in (1, 62):
+            os.environ["BK_COOP"] = "0"
+            one_cu = kernel_us(B)
+            os.environ.pop("BK_COOP")
+            coop = kernel_us(B)
+            small[f"B{B}"] = {"one_cu_per_board_us": one_cu[0], "cooperative_us": coop[0], "cooperative_launches": coop[1],
+                              "fallbacks": coop[2]}
+        if saved is not None:
+            os.environ["BK_COOP"] = saved
+
     # Secondary measurement (outside the timed region above): BASELINE configs[3] -- 512 self-play games,
     # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
     sp = None
@@ -433,6 +465,7 @@ def main():
             other_name: other,
             "cpu_baseline": cpu,
             "selfplay": sp,
+            "small_batch_latency": small,
             "collective_ranks_seen": dist.get_world_size() if dist is not None else 1,
             "collective_backend": (backend if dist is not None else None),
             "per_rank_leaf_evals_per_s": per_rank,

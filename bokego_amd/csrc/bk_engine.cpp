@@ -481,13 +481,13 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->dev_allocs.push_back(e->d_dev_flag);
     TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
     {
-        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (BK_COOP_MAX_TASKS + 2) * sizeof(unsigned int);
+        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE + 2) * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
         e->dev_allocs.push_back(e->d_coop_xchg);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_sync, sb));
         e->dev_allocs.push_back(e->d_coop_sync);
         TRY_CREATE(hipMemset(e->d_coop_sync, 0, sb));
-        e->d_coop_flag = e->d_coop_sync + BK_COOP_MAX_TASKS;
+        e->d_coop_flag = e->d_coop_sync + BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE;
     }
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
         // redo of a cooperative launch that gave up waiting: its counters are left anywhere
         if (a.coop_sync && blockIdx.x == 0)
-            for (int i = threadIdx.x; i < BK_COOP_MAX_TASKS; i += G::THREADS) a.coop_sync[i] = 0u;
+            for (int i = threadIdx.x; i < BK_COOP_MAX_TASKS; i += G::THREADS) a.coop_sync[i * BK_COOP_SYNC_STRIDE] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
     const bk_net_params& P = a.net[net];
     const int bg = net ? a.off_v + task - a.tasks_p : a.off_p + task;
     float* xb = a.coop_xchg + (size_t)task * F::XCHG_FLOATS;
-    unsigned int* cnt = a.coop_sync + task;
+    unsigned int* cnt = a.coop_sync + task * BK_COOP_SYNC_STRIDE;   // one counter per 256 B: polls spread over the L2 channels
 
     const int wc = wave / RH, rh = wave - wc * RH;
     const int wn = slice * F::CT + wc;                  // this wave's cout tile (of 8)
@@ -631,8 +631,10 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
         Wr1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 8192, 0));
     }
     if (tid == 0) dead = 0;
+    STAMP(0);
     stage_input<1, THREADS>(a, actb, bg, 1, tid);
     __syncthreads();
+    STAMP(1);
 
     const int kq = lane >> 4;
     f32x4 acc[RT][1];
@@ -664,6 +666,7 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
             if (xoff[rt] >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xr, xoff[rt] * 4, par, SC1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(3 + 4 * L);
         __syncthreads();
         const bool last = L == 6;
         if (a.coop_fault && L == 3 && task == 0 && slice == 1) return false;   // test hook: a peer that never arrives
@@ -685,6 +688,7 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
         }
         if (last && slice != 0) return false;           // uniform over the workgroup
         __syncthreads();
+        STAMP(4 + 4 * L);
         // the peers' slices: 81 points x (32 - 32/S) 16-byte chunks
         constexpr int OWN = 32 / S, PER = (81 * 32 + THREADS - 1) / THREADS;
         f32x4 v[PER];
@@ -702,12 +706,14 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
             }
         }
         __syncthreads();
+        STAMP(5 + 4 * L);
         return true;
     };
 
     // ---- layer 0: 5x5, 27 -> 128 ----
     load_bias<F>(bv, P.bias, wn, kq);
     conv_layer<F, true, true>(actb, P.wfrag, acc, lane, 0, wn, rowa0, Wr0, Wr1, Wr2, Wr3);
+    STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::L3_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -717,11 +723,13 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
     for (int L = 1; L < 7; ++L) {
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
         conv_layer<F, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, 0, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+        STAMP(2 + 4 * L);
         __syncthreads();
         if (!exchange(L)) return;
     }
     if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (wave == 0) run_heads<G>(a, P, actb, hs, net, lane, 0, bg);
+    STAMP(30);
 }
 
 template <int S, int RH>
@@ -811,6 +819,9 @@ int bk_coop_slices(int tasks, int n_cu) {
 }
 
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream) {
+    // wave grids measured (us per call at 2 / 63 tasks): 4 slices: 2 row groups 111 / 116, 3: 138 / 145, 6: 118 / 128;
+    // 8 slices: 6 row groups 86, 3: 84;  2 slices: 2 row groups 189 / 194, 3: 200 / 204.  Every wave arriving and polling
+    // for itself (no workgroup barriers around the meeting point): 177 at 63 tasks -- four times the pollers on the counters
     switch (slices) {
         case 8: return launch_coop<8, 6>(a, stream);
         case 4: return launch_coop<4, 2>(a, stream);
