@@ -14,6 +14,7 @@ import json
 import os
 import shlex
 import subprocess
+import sys
 import time
 
 import numpy as np
@@ -192,9 +193,11 @@ def play_game(black, white, komi=5.5, max_moves=162, opening=()):
             "ms_per_move": [1e3 * secs[i] / max(1, n[i]) for i in (0, 1)]}
 
 
-def play_match(a, b, n_games=10, komi=5.5, out_sgf=None, opening_plies=0, seed=0):
-    """a and b alternate colours; returns win counts and mean ms/move of each."""
+def play_match(a, b, n_games=10, komi=5.5, out_sgf=None, opening_plies=0, seed=0, progress=None):
+    """a and b alternate colours; returns win counts and mean ms/move of each.  progress: a file that gets one JSON
+    line of running totals per finished game (a match cut short still leaves its figures)."""
     wins, ms, games = [0, 0], [[], []], []
+    t_start = time.perf_counter()
     for gidx in range(n_games):
         a_black = gidx % 2 == 0
         op = random_opening(opening_plies, seed + gidx // 2) if opening_plies else ()
@@ -204,6 +207,10 @@ def play_match(a, b, n_games=10, komi=5.5, out_sgf=None, opening_plies=0, seed=0
         ms[0].append(g["ms_per_move"][0 if a_black else 1])
         ms[1].append(g["ms_per_move"][1 if a_black else 0])
         games.append({"a_black": a_black, **g})
+        if progress is not None:
+            print(json.dumps({"games": gidx + 1, a.name + "_wins": wins[0], b.name + "_wins": wins[1],
+                              "ms_per_move": {a.name: float(np.mean(ms[0])), b.name: float(np.mean(ms[1]))},
+                              "elapsed_s": time.perf_counter() - t_start}), file=progress, flush=True)
         if out_sgf:
             os.makedirs(os.path.dirname(os.path.abspath(out_sgf)), exist_ok=True)
             go.write_sgf(g["moves"], f"{out_sgf}_{gidx + 1}.sgf", komi=komi, B=a.name if a_black else b.name,
@@ -238,7 +245,7 @@ def main(argv=None):
         b = PolicyEngine(pi)
     else:
         b = SubprocessEngine(args.opponent)
-    res = play_match(a, b, args.games, args.komi, args.sgf, args.opening_plies, args.seed)
+    res = play_match(a, b, args.games, args.komi, args.sgf, args.opening_plies, args.seed, progress=sys.stderr)
     res.pop("records")
     print(json.dumps(res))
     a.close()

@@ -18,11 +18,21 @@ if REPO not in sys.path:
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("-r", type=int, default=1600)
-    ap.add_argument("--threads", type=int, default=0, help="torch CPU threads (0: torch's default)")
+    ap.add_argument("--threads", type=int, default=0,
+                    help="torch CPU threads (0: the cgroup CPU quota minus one for the match runner, else torch's default; "
+                         "torch's own default is every visible core -- 256 on a GPU box whose share is 16, i.e. 10x slower)")
     args = ap.parse_args(argv)
     import torch
-    if args.threads > 0:
-        torch.set_num_threads(args.threads)
+    threads = args.threads
+    if threads <= 0:
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                threads = max(1, int(int(q) / int(per)) - 1)
+        except (OSError, ValueError):
+            pass
+    if threads > 0:
+        torch.set_num_threads(threads)
     from bokego_amd.bkw import load_bkw
     from bokego_amd.gtp import NativeGTP
     from bokego_amd.mcts_native import Position
