@@ -33,7 +33,7 @@ for prec, pat in (("f32", "bk_leaf_eval_kernel<"), ("f16x2", "bk_leaf_eval_f16_k
     with open(os.path.join(dst, f"{tag}_kernel_stats_{prec}.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
-        w.writerows(r for r in rows if pat in r["Name"])
+        w.writerows(r for r in rows if pat in r["Name"] or (prec == "f32" and "bk_leaf_eval_coop_kernel<" in r["Name"]))
 
 
 def bench_block(prec):
