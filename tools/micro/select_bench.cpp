@@ -1,0 +1,90 @@
+// Microbenchmark behind the node layout of csrc/bk_tree.cpp: one PUCT select over 72 children (mcts.py:219-234) with
+// 232-byte nodes (position inside) and two divisions per child, with 48-byte nodes, with the child's average cached at
+// backprop, and with packed divisions.   g++ -O2 -std=c++17 -ffp-contract=off select_bench.cpp && ./a.out
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <random>
+#include <emmintrin.h>
+struct Pos { char b[192]; };
+struct Fat { Pos pos; double V = 0; int N = 0; float value = 0; uint8_t f[4]; int ko = 0, nk = 0, po = -1, mv = 0; };
+struct Slim { double V = 0; double avg = 0; int N = 0; int mv = 0; };
+template <class T> int sel_base(const std::vector<T>& nodes, const int* kids, int n, const double* prior, double c) {
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += nodes[kids[i]].N;
+    if (!total) total = 1;
+    const double sq = std::sqrt((double)total);
+    int best = -1; double bs = 0;
+    for (int i = 0; i < n; ++i) {
+        const T& k = nodes[kids[i]];
+        const double avg = k.N == 0 ? 0.0 : k.V / (double)k.N;
+        const double s = -avg + (c * prior[k.mv] * sq / (double)(1 + k.N));
+        if (best < 0 || s > bs) { best = kids[i]; bs = s; }
+    }
+    return best;
+}
+int sel_avg(const std::vector<Slim>& nodes, const int* kids, int n, const double* prior, double c) {
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += nodes[kids[i]].N;
+    if (!total) total = 1;
+    const double sq = std::sqrt((double)total);
+    int best = -1; double bs = 0;
+    for (int i = 0; i < n; ++i) {
+        const Slim& k = nodes[kids[i]];
+        const double s = -k.avg + (c * prior[k.mv] * sq / (double)(1 + k.N));
+        if (best < 0 || s > bs) { best = kids[i]; bs = s; }
+    }
+    return best;
+}
+int sel_sse(const std::vector<Slim>& nodes, const int* kids, int n, const double* prior, double c) {
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += nodes[kids[i]].N;
+    if (!total) total = 1;
+    const double sq = std::sqrt((double)total);
+    int best = -1; double bs = 0;
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        const Slim& k0 = nodes[kids[i]]; const Slim& k1 = nodes[kids[i + 1]];
+        __m128d num = _mm_set_pd(c * prior[k1.mv] * sq, c * prior[k0.mv] * sq);
+        __m128d den = _mm_set_pd((double)(1 + k1.N), (double)(1 + k0.N));
+        __m128d q = _mm_div_pd(num, den);
+        double u[2]; _mm_storeu_pd(u, q);
+        const double s0 = -k0.avg + u[0], s1 = -k1.avg + u[1];
+        if (best < 0 || s0 > bs) { best = kids[i]; bs = s0; }
+        if (s1 > bs) { best = kids[i + 1]; bs = s1; }
+    }
+    for (; i < n; ++i) {
+        const Slim& k = nodes[kids[i]];
+        const double s = -k.avg + (c * prior[k.mv] * sq / (double)(1 + k.N));
+        if (best < 0 || s > bs) { best = kids[i]; bs = s; }
+    }
+    return best;
+}
+int main() {
+    const int NK = 72, NPAR = 200;
+    std::mt19937 rng(1);
+    std::vector<Fat> fat(NPAR * NK + 1); std::vector<Slim> slim(NPAR * NK + 1);
+    std::vector<int> kids(NPAR * NK); std::vector<double> prior(81);
+    for (auto& p : prior) p = (rng() % 1000) / 40000.0;
+    for (int i = 0; i < NPAR * NK; ++i) {
+        kids[i] = i + 1;
+        int N = rng() % 50; double V = ((int)(rng() % 2000) - 1000) / 1000.0 * N;
+        fat[i + 1].N = N; fat[i + 1].V = V; fat[i + 1].mv = i % 81;
+        slim[i + 1].N = N; slim[i + 1].V = V; slim[i + 1].mv = i % 81; slim[i + 1].avg = N ? V / N : 0;
+    }
+    auto run = [&](const char* name, auto f) {
+        long acc = 0; const int REP = 20000;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < REP; ++r) { int p = r % NPAR; acc += f(&kids[p * NK]); }
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%-28s %7.1f ns per select (%d kids)  %.2f ns per child  [%ld]\n", name, 1e9 * dt / REP, NK, 1e9 * dt / REP / NK, acc);
+    };
+    for (int rep = 0; rep < 2; ++rep) {
+        run("fat nodes, 2 divisions", [&](const int* k) { return sel_base(fat, k, NK, prior.data(), 4.0); });
+        run("slim nodes, 2 divisions", [&](const int* k) { return sel_base(slim, k, NK, prior.data(), 4.0); });
+        run("slim nodes, cached avg", [&](const int* k) { return sel_avg(slim, k, NK, prior.data(), 4.0); });
+        run("slim, cached avg, divpd", [&](const int* k) { return sel_sse(slim, k, NK, prior.data(), 4.0); });
+    }
+}
