@@ -21,7 +21,7 @@ The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the refe
                 ranks + the end-of-generation all-reduce), per precision, with a CPU baseline at N=1.
   small_batch_latency  secondary: kernel time of the batches a single-tree genmove issues (configs[2]/[4]: 1 policy row +
                 ~60 value rows) and of a single position (configs[0]), one CU per board against the cooperative
-                cout-split launch (4 resp. 8 CUs per board; bit-identical outputs)
+                launch (4 resp. 12 CUs per board; bit-identical outputs)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -391,7 +391,7 @@ def main():
 
     # The genmove regime (BASELINE configs[2]/[4]: one tree, 1600 rollouts/move): expansion batches of one policy row +
     # 40..70 value rows, latency-bound.  Kernel time of such a batch with one CU per board against the cooperative
-    # cout-split launch (4 CUs per board here; 8 for the single position of configs[0]).
+    # launch (4 CUs per board here; 12 for the single position of configs[0]).
     small = None
     if rank == 0 and args.precision == "f32":
         def kernel_us(B, reps=20):

@@ -188,7 +188,7 @@ __device__ __forceinline__ int in_slot(int c) {
 // "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
 // PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
 // after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
-// F: the wave's tile set (Tiles<NB>, or CoopTiles<S, RH> of the cout-split small-batch kernel below).
+// F: the wave's tile set (Tiles<NB>, or CoopTiles<SC, SR, RH> of the cooperative small-batch kernel below).
 template <class F, bool FIRST, bool PRELOADED>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
                                                 f32x4 (&acc)[F::RT][F::CTW], int lane, int wm, int wn,
@@ -576,7 +576,10 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 // in global memory (L2), meets its S-1 peers at a counter and fetches their slices into its own LDS copy of the
 // activations.  Every dot product runs in the same k order on the same instruction as in the forms above, so the
 // results are bit-identical to theirs.
-//   * waves: (8/S cout tiles) x (RH groups of 6/RH position tiles); weights, biases, LDS layout: as for 1 board;
+//   * a second split serves 65..80 tasks, where only 3 CUs per board are to be had and 8 cout tiles do not divide by 3:
+//     SR = 3 slices of two 16-point tiles each, all 128 output channels.  In general SC cout ranges x SR point ranges
+//     (a slice fetches everything it did not compute itself): 8x1, 4x1, 2x1, 1x3, and 2x3 / 4x3 for the smallest batches;
+//   * waves: (8/SC cout tiles) x (RH groups of 6/SR/RH position tiles); weights, biases, LDS layout: as for 1 board;
 //   * exchange buffer: [task][layer parity][point][128 slots] fp32 -- a workgroup that is one layer ahead writes the other
 //     parity, and cannot get two ahead before every peer has arrived at the counter in between;
 //   * the meeting point: one thread adds 1 to the task's counter (release, agent scope: peers may sit on another XCD
@@ -587,23 +590,26 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 //     without the peers (the card shared with something that holds CUs for that long) the workgroup raises
 //     coop_err = coop_tag and runs on to the end, and the gated launch the engine enqueues behind every cooperative one
 //     recomputes the batch with the one-CU form and clears the counters.
-template <int S, int RH>
+template <int SC, int SR, int RH>
 struct CoopTiles {
-    static_assert((S == 2 || S == 4 || S == 8) && 6 % RH == 0, "slices of 64 / 32 / 16 output channels");
-    static constexpr int RT = 6 / RH, CTW = 1;
+    static_assert((SC == 1 || SC == 2 || SC == 4 || SC == 8) && (SR == 1 || SR == 3) && (6 / SR) % RH == 0 && SC * SR > 1,
+                  "SC slices of 128/SC output channels x SR slices of 6/SR position tiles");
+    static constexpr int S = SC * SR;                   // workgroups per board
+    static constexpr int ROWT = 6 / SR;                 // position tiles per workgroup
+    static constexpr int RT = ROWT / RH, CTW = 1;
     static constexpr int A0 = 0, A1 = RT, X0 = -1, X1 = -1, Y0a = -1, Y0b = -1, Y1 = -1;
     static constexpr bool WM_EDGES = false;
-    static constexpr int CT = 8 / S;                    // cout tiles per workgroup
+    static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = CT * RH, THREADS = 64 * NW;
     static constexpr int XCHG_FLOATS = 2 * 81 * 128;    // per task: two layer parities
 };
 constexpr int COOP_SPIN_LIMIT = 1 << 15;
 
-template <int S, int RH>
-__global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop_kernel(const bk_eval_args a) {
+template <int SC, int SR, int RH>
+__global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval_coop_kernel(const bk_eval_args a) {
     using G = Geo<1>;
-    using F = CoopTiles<S, RH>;
-    constexpr int THREADS = F::THREADS, RT = F::RT;
+    using F = CoopTiles<SC, SR, RH>;
+    constexpr int THREADS = F::THREADS, RT = F::RT, S = F::S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
     const int dummy_byte = G::L3_BYTES;
@@ -622,8 +628,9 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
     float* xb = a.coop_xchg + (size_t)task * F::XCHG_FLOATS;
     unsigned int* cnt = a.coop_sync + task * BK_COOP_SYNC_STRIDE;   // one counter per 256 B: polls spread over the L2 channels
 
+    const int sc = slice % SC, sr = slice / SC;         // this workgroup's cout range and point range
     const int wc = wave / RH, rh = wave - wc * RH;
-    const int wn = slice * F::CT + wc;                  // this wave's cout tile (of 8)
+    const int wn = sc * F::CT + wc;                     // this wave's cout tile (of 8)
     f32x4 Wr0[1], Wr1[1], Wr2[1], Wr3[1];
     {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
@@ -641,7 +648,7 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
     int rowa0[RT], rowa3[RT], storea[RT], xoff[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const TileRow fr = tile_row<1>(0, rh * RT + rt, lane & 15);
+        const TileRow fr = tile_row<1>(0, sr * F::ROWT + rh * RT + rt, lane & 15);
         rowa0[rt] = G::addr0(0, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
         rowa3[rt] = G::addr3(0, fr.y, fr.x) - RP3 - REC3 + kq * 16;
         storea[rt] = fr.valid ? G::addr3(0, fr.y, fr.x) + (16 * wn + 4 * kq) * 4 : dummy_byte;
@@ -689,18 +696,19 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
         if (last && slice != 0) return false;           // uniform over the workgroup
         __syncthreads();
         STAMP(4 + 4 * L);
-        // the peers' slices: 81 points x (32 - 32/S) 16-byte chunks
-        constexpr int OWN = 32 / S, PER = (81 * 32 + THREADS - 1) / THREADS;
+        // the peers' slices: every 16-byte chunk (point q, channels 4c..4c+3) this workgroup did not compute itself
+        constexpr int OWN = 32 / SC, PER = (81 * 32 + THREADS - 1) / THREADS;
+        auto foreign = [&](int i) { return i < 81 * 32 && !(((i & 31) / OWN) == sc && ((i >> 5) >> 4) / F::ROWT == sr); };
         f32x4 v[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = tid + THREADS * k, c = i & 31;
-            if (i < 81 * 32 && (c / OWN) != slice) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, i * 16, par, SC1));
+            const int i = tid + THREADS * k;
+            if (foreign(i)) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, i * 16, par, SC1));
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + THREADS * k, q = i >> 5, c = i & 31;
-            if (i < 81 * 32 && (c / OWN) != slice) {
+            if (foreign(i)) {
                 const int y = q / 9, x = q - 9 * y;
                 *reinterpret_cast<f32x4*>(actb + G::addr3(0, y, x) + c * 16) = v[k];
             }
@@ -732,12 +740,13 @@ __global__ void __launch_bounds__((CoopTiles<S, RH>::THREADS)) bk_leaf_eval_coop
     STAMP(30);
 }
 
-template <int S, int RH>
+template <int SC, int SR, int RH>
 hipError_t launch_coop(const bk_eval_args& a, hipStream_t stream) {
+    constexpr int S = SC * SR;
     static bool attr_set_dev[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    auto kern = bk_leaf_eval_coop_kernel<S, RH>;
+    auto kern = bk_leaf_eval_coop_kernel<SC, SR, RH>;
     if (!attr_set_dev[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -749,7 +758,7 @@ hipError_t launch_coop(const bk_eval_args& a, hipStream_t stream) {
     const int tasks = args.tasks_p + args.tasks_v;
     if (tasks == 0) return hipSuccess;
     const int grid = (tasks + 7) / 8 * 8 * S;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CoopTiles<S, RH>::THREADS), Geo<1>::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CoopTiles<SC, SR, RH>::THREADS), Geo<1>::LDS_BYTES, stream, args);
     return hipGetLastError();
 }
 
@@ -808,13 +817,17 @@ int bk_coop_slices(int tasks, int n_cu) {
     if (const char* f = getenv("BK_COOP")) {
         const int v = atoi(f);
         if (v == 0) return 0;
-        if ((v == 2 || v == 4 || v == 8) && (tasks + 7) / 8 * 8 * v <= 2 * n_cu) return v;
+        if ((v == 2 || v == 3 || v == 4 || v == 6 || v == 8 || v == 12) && (tasks + 7) / 8 * 8 * v <= 2 * n_cu) return v;
     }
-    // measured (tools/coop_probe.py, us per call incl. the gated launch; one CU per board: 330):
-    //   8 CUs per board: 92 (2 tasks) .. 110 (17) .. 114 (32);  4: 111 (2) .. 117 (63);  2: 188 (2) .. 197 (128)
-    if (tasks * 16 <= n_cu) return 8;
-    if (tasks * 4 <= n_cu) return 4;
-    if (tasks * 2 <= n_cu) return 2;
+    // measured (tools/coop_probe.py, us per call incl. the gated launch; one CU per board: 330), CUs per board:
+    //   12 (4 cout x 3 point ranges): 68 at 2 tasks (8: 85), 106 at 9;   8: 104 .. 106 (9 .. 32 tasks);   6 (2 x 3): 104 .. 107
+    //   (.. 33);   4: 111 .. 112 (.. 64);   3 (point ranges): 146 (.. 80);   2: 190 (.. 128)
+    // blocks are dealt to the 8 XCDs in turn and task t sits on XCD t % 8: what has to fit is ceil(tasks / 8) groups on the
+    // n_cu / 8 CUs of one XCD (85 tasks x 3 slices = 255 workgroups, but 33 of them on each of five XCDs: 239 us)
+    const int per_xcd = (tasks + 7) / 8, cus = n_cu / 8;
+    if (per_xcd == 1 && 12 <= cus) return 12;
+    for (int sl : {8, 6, 4, 3, 2})
+        if (per_xcd * sl <= cus) return sl;
     return 0;
 }
 
@@ -823,9 +836,12 @@ hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream
     // 8 slices: 6 row groups 86, 3: 84;  2 slices: 2 row groups 189 / 194, 3: 200 / 204.  Every wave arriving and polling
     // for itself (no workgroup barriers around the meeting point): 177 at 63 tasks -- four times the pollers on the counters
     switch (slices) {
-        case 8: return launch_coop<8, 6>(a, stream);
-        case 4: return launch_coop<4, 2>(a, stream);
-        default: return launch_coop<2, 2>(a, stream);
+        case 12: return launch_coop<4, 3, 2>(a, stream);  // 4 cout ranges x 3 point ranges: 4 waves x 1 tile
+        case 6: return launch_coop<2, 3, 2>(a, stream);   // 2 x 3: 8 waves x 1 tile
+        case 8: return launch_coop<8, 1, 6>(a, stream);
+        case 4: return launch_coop<4, 1, 2>(a, stream);
+        case 3: return launch_coop<1, 3, 1>(a, stream);   // 3 point ranges x all 128 channels: 8 waves x 2 tiles
+        default: return launch_coop<2, 1, 2>(a, stream);
     }
 }
 

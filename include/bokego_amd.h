@@ -91,7 +91,7 @@ typedef struct bk_stats_t {
     uint64_t f16_device_overflow;    /* bk_eval_device* calls redone in fp32 (gated launch on the caller's stream) for the same reason */
     uint64_t positions_encoded;      /* position records turned into feature planes on the GPU */
     uint64_t split_launches;         /* evaluations run as whole rounds of 3-board workgroups + a shorter tail launch */
-    uint64_t coop_launches;          /* small fp32 batches run with 2/4/8 CUs per board (cooperative cout-split launch) */
+    uint64_t coop_launches;          /* small fp32 batches run with 2..12 CUs per board (cooperative launch) */
     uint64_t coop_fallbacks;         /* ... of which redone by the one-CU form because a workgroup gave up waiting for its peers */
 } bk_stats_t;
 

@@ -441,7 +441,8 @@ def _small_batches(eng, x):
 
 
 def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
-    """Small fp32 batches on the engine's stream run with 8 / 4 / 2 CUs per board (cout-split cooperative kernel,
+    """Small fp32 batches on the engine's stream run with 12 / 8 / 6 / 4 / 3 / 2 CUs per board (cooperative kernel: output
+    channels split 8, 4 or 2 ways and / or the board's points split 3 ways;
     bk_stats().coop_launches): every output bit-identical to the one-CU-per-board form (BK_COOP=0), for each slice
     count forced over the whole range as well as for the engine's own choice, with no fallback taken."""
     from bokego_amd.engine import LeafEngine
@@ -452,14 +453,14 @@ def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
     monkeypatch.setenv("BK_COOP", "0")
     ref = _small_batches(eng, x)
     assert eng.stats()["coop_launches"] == 0
-    for mode in (None, "2", "4", "8"):
+    for mode in (None, "2", "3", "4", "6", "8", "12"):
         if mode is None:
             monkeypatch.delenv("BK_COOP")
         else:
             monkeypatch.setenv("BK_COOP", mode)
         c0 = eng.stats()["coop_launches"]
         got = _small_batches(eng, x)
-        assert eng.stats()["coop_launches"] - c0 >= (13 if mode in (None, "2") else 8), mode
+        assert eng.stats()["coop_launches"] - c0 >= (13 if mode in (None, "2", "3") else 6), mode
         for a, b in zip(ref, got):
             for k in a:
                 assert np.array_equal(a[k], b[k]), (mode, k, a[k].shape)
@@ -483,7 +484,7 @@ def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
     x = make_batch(2048, seed_base=99_000, dtype=np.uint8)
     pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
     eng, other = LeafEngine(pw, vw, max_batch=256), LeafEngine(pw, vw, max_batch=2048)
-    sizes = (1, 7, 33, 62, 90)
+    sizes = (1, 7, 33, 62, 70, 90)
     first = {B: eng.eval(x[:B], probs=True, value=True, n_policy=min(B, 3)) for B in sizes}
     pending = []
     for i in range(300):

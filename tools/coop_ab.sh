@@ -2,5 +2,6 @@
 set -e
 cd /root/repo
 export PYTHONPATH=/root/repo
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cooperative"
+timeout -k 10 200 python tools/coop_probe.py
 timeout -k 10 200 python tools/genmove_probe.py 40
-timeout -k 10 600 python -m pytest tests/test_gpu_mcts.py tests/test_gpu_selfplay.py -x -q -m gpu

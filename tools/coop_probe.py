@@ -1,4 +1,4 @@
-"""Kernel time of small batches: the one-CU-per-board form against the cooperative form with 2 / 4 / 8 CUs per board.
+"""Kernel time of small batches: the one-CU-per-board form against the cooperative form with 2 .. 12 CUs per board.
     python tools/coop_probe.py          (BK_COOP=0|2|4|8 in the environment forces one form)"""
 import os
 import sys
@@ -15,7 +15,7 @@ eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.jo
 x = make_batch(512, seed_base=1, dtype=np.uint8)
 eng.set_profiling(True)
 print("BK_COOP =", os.environ.get("BK_COOP", "(default)"))
-for B in (1, 8, 16, 31, 32, 48, 62, 63, 64, 100, 127, 200):
+for B in (1, 8, 16, 31, 32, 48, 62, 63, 64, 70, 84, 85, 100, 127, 200):
     for _ in range(3):
         eng.eval(x[:B], probs=True, value=True, n_policy=1)
     s0 = eng.stats()
