@@ -445,9 +445,13 @@ __device__ __forceinline__ void run_heads(const bk_eval_args& a, const bk_net_pa
         hv[lane] = fmaxf(s[0], 0.f);
         if (lane + 64 < 81) hv[lane + 64] = fmaxf(s[1], 0.f);
         __builtin_amdgcn_wave_barrier();
+        // all 81 rows of lin1 in flight at once (one L2 latency instead of nine), then the sum in its order
+        float w1[81];
+#pragma unroll
+        for (int q = 0; q < 81; ++q) w1[q] = P.lin1_wt[q * 64 + lane];
         float z = P.lin1_b[lane];
-#pragma unroll 9
-        for (int q = 0; q < 81; ++q) z += P.lin1_wt[q * 64 + lane] * hv[q];
+#pragma unroll
+        for (int q = 0; q < 81; ++q) z += w1[q] * hv[q];
         z = fmaxf(z, 0.f);
         const float v = wave_sum(z * P.lin2_w[lane]) + P.lin2_b;
         if (lane == 0 && a.values) a.values[bg] = tanhf(v);
