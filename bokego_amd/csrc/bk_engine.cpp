@@ -71,12 +71,10 @@ struct bk_engine {
     // call's fp32 redo kernel), [1] = number of calls redone
     unsigned int* d_dev_flag = nullptr;
     unsigned int dev_seq = 0;
-    // cooperative small-batch launches (compute stream only: one exchange buffer): d_coop_sync[BK_COOP_MAX_TASKS] arrival
-    // counters; d_coop_flag[0] = tag of the last launch that gave up waiting, [1] = launches redone by the one-CU form
+    // cooperative small-batch launches (ticket path on the compute stream only: one exchange buffer): the exchange buffer
+    // and the per-task arrival counters, BK_COOP_SYNC_STRIDE words apart
     float* d_coop_xchg = nullptr;
     unsigned int* d_coop_sync = nullptr;
-    unsigned int* d_coop_flag = nullptr;
-    unsigned int coop_seq = 0;
     unsigned long long* d_stamps = nullptr;  // diagnostic builds only
 };
 
@@ -271,7 +269,7 @@ void drain_events(bk_engine* e) {
 // gated on d_flag[0] == tag -- stream-ordered, no host round trip, and a few microseconds when nothing overflowed.
 int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, int want, float* d_logits,
             float* d_probs, float* d_values, hipStream_t stream, int precision, unsigned int* d_flag,
-            unsigned int tag = 1, bool gated_redo = false) {
+            unsigned int tag = 1, bool gated_redo = false, bool allow_coop = false) {
     if (B == 0) return BK_OK;
     bk_eval_args a{};
     a.net[0] = e->net[0];
@@ -312,22 +310,17 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         r.gate_tag = tag;
         return bk_launch_leaf_eval(r, nb, stream);
     };
-    // Small batches on the engine's own stream: S CUs per board (bk_kernels.hip, "cout-split form"), followed by the
-    // one-CU form gated on the cooperative launch having given up (stream-ordered, ~4 us when it did not).
-    if (const int slices = (precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && !getenv("BK_FORCE_NB"))
-                               ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0) {
-        if (++e->coop_seq == 0) e->coop_seq = 1;
+    // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
+    // "cooperative form").  A workgroup that gives up waiting for its peers raises word 1 of the slot's flag block, which
+    // travels to the host with the outputs: bk_wait then redoes the request with the one-CU form.
+    if (const int slices = (allow_coop && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag &&
+                            !getenv("BK_FORCE_NB")) ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0) {
         a.coop_xchg = e->d_coop_xchg;
         a.coop_sync = e->d_coop_sync;
-        a.coop_err = e->d_coop_flag;
-        a.coop_tag = e->coop_seq;
+        a.coop_err = d_flag + 1;
+        a.coop_tag = 1;
         a.coop_fault = getenv("BK_COOP_FAULT") != nullptr;
         HIP_TRY(e, bk_launch_leaf_eval_coop(a, slices, stream));
-        bk_eval_args r = a;
-        r.overflow = nullptr;
-        r.gate = e->d_coop_flag;
-        r.gate_tag = e->coop_seq;
-        HIP_TRY(e, bk_launch_leaf_eval(r, 1, stream));
         e->st.coop_launches += 1;
         if (timed) {
             HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
@@ -481,13 +474,12 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->dev_allocs.push_back(e->d_dev_flag);
     TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
     {
-        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE + 2) * sizeof(unsigned int);
+        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
         e->dev_allocs.push_back(e->d_coop_xchg);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_sync, sb));
         e->dev_allocs.push_back(e->d_coop_sync);
         TRY_CREATE(hipMemset(e->d_coop_sync, 0, sb));
-        e->d_coop_flag = e->d_coop_sync + BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE;
     }
     for (auto& s : e->slots)
         if ((rc = alloc_slot(e, s))) return bail(rc);
@@ -567,13 +559,13 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         s->off_logits = s->off_probs + (((want & BK_WANT_PROBS) ? (size_t)n_policy * 81 * 4 : 0) + 63) / 64 * 64;
         s->out_bytes = s->off_logits + ((want & BK_WANT_LOGITS) ? (size_t)n_policy * 81 * 4 : 0);
         unsigned int* d_flag = reinterpret_cast<unsigned int*>(s->d_out);
-        if (s->flag_dirty) {  // only after an overflow was seen: the flag is zero otherwise
-            HIP_TRY(e, hipMemsetAsync(d_flag, 0, sizeof(unsigned int), e->stream));
+        if (s->flag_dirty) {  // only after a flag was seen raised: both words are zero otherwise
+            HIP_TRY(e, hipMemsetAsync(d_flag, 0, 2 * sizeof(unsigned int), e->stream));
             s->flag_dirty = false;
         }
         rc = enqueue(e, s->d_in, dtype, B, n_policy, want, reinterpret_cast<float*>(s->d_out + s->off_logits),
                      reinterpret_cast<float*>(s->d_out + s->off_probs), reinterpret_cast<float*>(s->d_out + s->off_values),
-                     e->stream, e->precision, d_flag);
+                     e->stream, e->precision, d_flag, 1, false, /*allow_coop=*/true);
         if (rc) return rc;
         if (chained) {
             HIP_TRY(e, hipEventRecord(s->computed, e->stream));
@@ -637,9 +629,17 @@ int bk_wait(bk_engine* e, int64_t ticket) {
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
         HIP_TRY(e, hipEventSynchronize(s.done));
-        if (s.B > 0 && *reinterpret_cast<unsigned int*>(s.h_out)) {
-            // the f16x2 kernel clamped an activation: redo this request on the exact fp32 kernel
-            e->st.f16_overflow_fallbacks += 1;
+        const unsigned int* hf = reinterpret_cast<const unsigned int*>(s.h_out);
+        if (s.B > 0 && (hf[0] || hf[1])) {
+            // word 0: the f16x2 kernel clamped an activation -- redo this request on the exact fp32 kernel;
+            // word 1: a workgroup of the cooperative launch gave up waiting for its peers -- redo with one CU per board
+            // (the arrival counters are left anywhere: clear them)
+            if (hf[1]) {
+                e->st.coop_fallbacks += 1;
+                HIP_TRY(e, hipMemsetAsync(e->d_coop_sync, 0, (size_t)BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE * sizeof(unsigned int), e->stream));
+            } else {
+                e->st.f16_overflow_fallbacks += 1;
+            }
             s.flag_dirty = true;
             int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, reinterpret_cast<float*>(s.d_out + s.off_logits),
                              reinterpret_cast<float*>(s.d_out + s.off_probs), reinterpret_cast<float*>(s.d_out + s.off_values),
@@ -647,7 +647,7 @@ int bk_wait(bk_engine* e, int64_t ticket) {
             if (rc) return rc;
             HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, s.out_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(e, hipStreamSynchronize(e->stream));
-            *reinterpret_cast<unsigned int*>(s.h_out) = 0;
+            std::memset(s.h_out, 0, 2 * sizeof(unsigned int));
         }
         if (s.want & BK_WANT_LOGITS) std::memcpy(s.logits, s.h_out + s.off_logits, (size_t)s.n_policy * 81 * 4);
         if (s.want & BK_WANT_PROBS) std::memcpy(s.probs, s.h_out + s.off_probs, (size_t)s.n_policy * 81 * 4);
@@ -733,13 +733,6 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
         HIP_TRY(e, hipDeviceSynchronize());  // the calls may sit on any caller stream
         HIP_TRY(e, hipMemcpy(f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
         e->st.f16_device_overflow = f[1];
-    }
-    if (e->d_coop_flag && e->coop_seq) {
-        unsigned int f[2] = {0, 0};
-        HIP_TRY(e, hipSetDevice(e->device));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        HIP_TRY(e, hipMemcpy(f, e->d_coop_flag, sizeof(f), hipMemcpyDeviceToHost));
-        e->st.coop_fallbacks = f[1];
     }
     *out = e->st;
     return BK_OK;

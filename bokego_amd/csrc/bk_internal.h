@@ -61,7 +61,7 @@ struct bk_eval_args {
     int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
     // cooperative (cout-split) launches for small batches, bk_kernels.hip: exchange buffer [BK_COOP_MAX_TASKS][2][81][128]
     // fp32, one arrival counter per task (zero between launches), and the flag a workgroup raises to coop_tag when its
-    // peers did not show up in time (the gated redo behind it then runs for real)
+    // peers did not show up in time (word 1 of the ticket's flag block: bk_wait then redoes the request)
     float* coop_xchg;
     unsigned int* coop_sync;
     unsigned int* coop_err;

@@ -467,9 +467,6 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
         if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
-        // redo of a cooperative launch that gave up waiting: its counters are left anywhere
-        if (a.coop_sync && blockIdx.x == 0)
-            for (int i = threadIdx.x; i < BK_COOP_MAX_TASKS; i += G::THREADS) a.coop_sync[i * BK_COOP_SYNC_STRIDE] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
@@ -592,8 +589,8 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 //     dealing of blocks to XCDs they share an L2 and follow each other in that XCD's dispatch order (a partly resident
 //     group waits only for blocks that are dispatched before any later group's).  The poll is BOUNDED: after ~20 ms
 //     without the peers (the card shared with something that holds CUs for that long) the workgroup raises
-//     coop_err = coop_tag and runs on to the end, and the gated launch the engine enqueues behind every cooperative one
-//     recomputes the batch with the one-CU form and clears the counters.
+//     the flag coop_err, which travels to the host with the outputs, and runs on to the end; bk_wait then clears the counters
+//     and recomputes the request with the one-CU form.
 template <int SC, int SR, int RH>
 struct CoopTiles {
     static_assert((SC == 1 || SC == 2 || SC == 4 || SC == 8) && (SR == 1 || SR == 3) && (6 / SR) % RH == 0 && SC * SR > 1,
