@@ -820,7 +820,7 @@ int bk_coop_slices(int tasks, int n_cu) {
         if (v == 0) return 0;
         if ((v == 2 || v == 3 || v == 4 || v == 6 || v == 8 || v == 12) && (tasks + 7) / 8 * 8 * v <= 2 * n_cu) return v;
     }
-    // measured (tools/coop_probe.py, us per call incl. the gated launch; one CU per board: 330), CUs per board:
+    // measured (tools/coop_probe.py, us per call; one CU per board: 330), CUs per board:
     //   12 (4 cout x 3 point ranges): 68 at 2 tasks (8: 85), 106 at 9;   8: 104 .. 106 (9 .. 32 tasks);   6 (2 x 3): 104 .. 107
     //   (.. 33);   4: 111 .. 112 (.. 64);   3 (point ranges): 146 (.. 80);   2: 190 (.. 128)
     // blocks are dealt to the 8 XCDs in turn and task t sits on XCD t % 8: what has to fit is ceil(tasks / 8) groups on the

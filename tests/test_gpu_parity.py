@@ -506,7 +506,8 @@ def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
 
 def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
     """BK_COOP_FAULT makes one slice of one board leave before a meeting point: its peers give up after the bounded
-    wait, the gated one-CU launch behind the cooperative one recomputes the batch (bk_stats().coop_fallbacks), the
+    wait and raise the flag that travels with the outputs, bk_wait redoes the request with one CU per board
+    (bk_stats().coop_fallbacks), the
     outputs are the usual bits, and the next cooperative launch finds its counters clean."""
     from bokego_amd.engine import LeafEngine
     from bokego_amd.workload import make_batch
