@@ -1,0 +1,40 @@
+"""-m gpu: bench.py's one-line contract on a short run (the driver's invocation with fewer steps and without the CPU and
+self-play legs): the keys the driver reads, the headline's arithmetic, roofline consistency, parity measured in the run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--sustain", "0.3",
+                          "--no-cpu-baseline", "--no-selfplay"], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py prints exactly one line"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "leaf-evals/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    B = d["config"]["batch_per_gpu"]
+    assert abs(d["value"] - B * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.01
+    par = d["config"]["parity"]
+    assert par["max_abs_dlogit"] < 1e-4 and par["max_abs_dprob"] < 1e-5 and par["max_abs_dvalue"] < 1e-4
+    f16 = d["f16x2"]
+    assert f16["roofline"]["peak"] == 2500.0 and f16["value"] > d["value"]
+    sb = d["small_batch_latency"]
+    assert sb["B62"]["cooperative_us"] < 0.6 * sb["B62"]["one_cu_per_board_us"] and sb["B62"]["fallbacks"] == 0
