@@ -570,27 +570,30 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     STAMP(30);
 }
 
-// ---- the cout-split form for small batches -------------------------------------------------------------------------------
+// ---- the cooperative form for small batches ----------------------------------------------------------------------------
 // With fewer one-board tasks than CUs the form above leaves most of the chip idle and a batch takes the 0.33 ms one CU
-// needs for a whole network (a 1600-rollout genmove is ~10 such batches of 40..80 boards).  Here S workgroups on S CUs
-// share ONE board of one net: each computes 128/S output channels of every layer for all 81 points, publishes its slice
-// in global memory (L2), meets its S-1 peers at a counter and fetches their slices into its own LDS copy of the
-// activations.  Every dot product runs in the same k order on the same instruction as in the forms above, so the
-// results are bit-identical to theirs.
-//   * a second split serves 65..80 tasks, where only 3 CUs per board are to be had and 8 cout tiles do not divide by 3:
-//     SR = 3 slices of two 16-point tiles each, all 128 output channels.  In general SC cout ranges x SR point ranges
-//     (a slice fetches everything it did not compute itself): 8x1, 4x1, 2x1, 1x3, and 2x3 / 4x3 for the smallest batches;
+// needs for a whole network (a 1600-rollout genmove is ~10 such batches of 40..80 boards).  Here S = SC x SR workgroups on
+// S CUs share ONE board of one net: each computes one of SC ranges of output channels for one of SR ranges of the board's
+// points in every layer, publishes that slice in global memory (L2), meets its S-1 peers at a counter and fetches what
+// they computed into its own LDS image of the activations.  Every dot product runs in the same k order on the same
+// instruction as in the forms above, so the results are bit-identical to theirs.
+//   * splits: 8x1, 4x1, 2x1 (output channels only); 1x3 for 65..80 tasks, where only 3 CUs per board are to be had and 8
+//     cout tiles do not divide by 3 (three ranges of two 16-point tiles, all 128 channels); 2x3 and 4x3 for the smallest
+//     batches.  bk_coop_slices() picks by task count;
 //   * waves: (8/SC cout tiles) x (RH groups of 6/SR/RH position tiles); weights, biases, LDS layout: as for 1 board;
 //   * exchange buffer: [task][layer parity][point][128 slots] fp32 -- a workgroup that is one layer ahead writes the other
 //     parity, and cannot get two ahead before every peer has arrived at the counter in between;
-//   * the meeting point: one thread adds 1 to the task's counter (release, agent scope: peers may sit on another XCD
-//     with another L2) and polls until all S arrivals of this layer are in; the counter runs 0 .. 7S and the slice that
-//     computes the heads puts it back to 0.  blocks x + 8(S j + s) are the S slices of task 8j + x: with the round-robin
-//     dealing of blocks to XCDs they share an L2 and follow each other in that XCD's dispatch order (a partly resident
-//     group waits only for blocks that are dispatched before any later group's).  The poll is BOUNDED: after ~20 ms
-//     without the peers (the card shared with something that holds CUs for that long) the workgroup raises
-//     the flag coop_err, which travels to the host with the outputs, and runs on to the end; bk_wait then clears the counters
-//     and recomputes the request with the one-CU form.
+//   * coherence (peers may sit on another XCD with another L2) without cache-wide fences: slices are written and read with
+//     device-scope (sc1) buffer accesses, every wave waits for its stores to be acknowledged before the workgroup
+//     barrier, then ONE thread adds 1 to the task's counter (device-scope atomic) and polls until all S arrivals of this
+//     layer are in.  The counter runs 0 .. 7S and the slice that computes the heads puts it back to 0;
+//   * placement: blocks x + 8(S j + s) are the S slices of task 8j + x: with the round-robin dealing of blocks to XCDs they
+//     share an L2 and follow each other in that XCD's dispatch order (a partly resident group waits only for blocks that
+//     are dispatched before any later group's).  Speed only; nothing above depends on it;
+//   * the poll is BOUNDED (COOP_SPIN_LIMIT polls, ~50 ms): if the peers do not show up -- the card shared with something
+//     that holds CUs for that long -- the workgroup raises the flag coop_err, which travels to the host with the outputs,
+//     and runs on to the end (the grid always drains); bk_wait then clears the counters and recomputes the request with
+//     the one-CU form.
 template <int SC, int SR, int RH>
 struct CoopTiles {
     static_assert((SC == 1 || SC == 2 || SC == 4 || SC == 8) && (SR == 1 || SR == 3) && (6 / SR) % RH == 0 && SC * SR > 1,
