@@ -21,6 +21,8 @@
 //     same kernel.
 // HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2 resident).  BatchNorm (eval
 // mode) is folded into the weights on the host in fp64.
+// Batches of at most 128 (net, board) tasks take the cooperative form further down instead: 2 .. 12 workgroups on as
+// many CUs share one board, each computing a slice of every layer and exchanging slices through L2 (same bits).
 // History: round 1 used 32-row tiles (v_mfma_f32_32x32x2_f32), an XOR-swizzled LDS layout and one wave per
 // SIMD; every later form was checked bit-identical to it on the GPU (tools/ab_bits.py), which is why the channel slots of
 // layers 0..5 are kept in the permuted order bk_slot_perm: it reproduces that kernel's summation order.
