@@ -72,6 +72,7 @@ SYMBOLS = {
     "bk_engine_set_profiling": (ctypes.c_int, [_P, ctypes.c_int]),
     "bk_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "bk_engine_max_batch": (ctypes.c_int, [_P]),
+    "bk_plan_query": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_engine_synchronize": (ctypes.c_int, [_P]),
     "bk_last_error": (ctypes.c_char_p, [_P]),
 }

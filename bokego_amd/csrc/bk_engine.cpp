@@ -740,6 +740,12 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
 
 int bk_engine_max_batch(bk_engine* e) { return e ? e->max_batch : BK_ERR_ARG; }
 
+int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int* boards_per_workgroup) {
+    if (n_policy < 0 || n_value < 0 || n_cu <= 0 || (precision != BK_PRECISION_F32 && precision != BK_PRECISION_F16X2)) return BK_ERR_ARG;
+    if (boards_per_workgroup) *boards_per_workgroup = bk_pick_nb(n_policy, n_value, n_cu, precision);
+    return precision == BK_PRECISION_F32 ? bk_coop_slices(n_policy + n_value, n_cu) : 0;
+}
+
 #ifdef BK_STAMPS
 // diagnostic builds only (not part of include/bokego_amd.h)
 int bk_debug_read_stamps(bk_engine* e, unsigned long long* out, int n_blocks) {

@@ -184,6 +184,14 @@ int bk_engine_get_precision(bk_engine *e);
 int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every kernel launch */
 int bk_stats(bk_engine *e, bk_stats_t *out);
 int bk_engine_max_batch(bk_engine *e);
+
+/*
+ * Launch planner, as a pure function (no engine, no GPU): how a request of n_policy PolicyNet rows + n_value ValueNet
+ * rows would be launched on a device with n_cu compute units at `precision`.  Returns the CUs per board of the
+ * cooperative small-batch form (12/8/6/4/3/2; ticket path, fp32 only), or 0 when the ordinary form runs;
+ * *boards_per_workgroup (may be NULL) receives the ordinary form's workgroup size (1..3) for a single launch.
+ */
+int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int *boards_per_workgroup);
 int bk_engine_synchronize(bk_engine *e);
 const char *bk_last_error(bk_engine *e); /* e == NULL: last error of a failed create */
 

@@ -154,3 +154,22 @@ def test_comm_library_symbols_and_cpu_errors():
         assert b"device_id" in lib.bk_comm_last_error()
         assert lib.bk_comm_init(2, 1, ident, 0, ctypes.byref(h)) != 0       # rank >= world
         assert lib.bk_comm_allreduce_sum_f64(None, None, 3) != 0
+
+
+def test_launch_planner_choices(lib, monkeypatch):
+    """bk_plan_query: the planner's decisions as a pure function -- CUs per board of the cooperative small-batch form by
+    task count (what fits is ceil(tasks / 8) groups on the n_cu / 8 CUs of an XCD) and boards per workgroup otherwise."""
+    for v in ("BK_COOP", "BK_FORCE_NB"):
+        monkeypatch.delenv(v, raising=False)
+    nb = ctypes.c_int(0)
+    q = lambda npol, nval, prec=0, n_cu=256: lib.bk_plan_query(npol, nval, n_cu, prec, ctypes.byref(nb))  # noqa: E731
+    assert [q(1, 1), q(1, 7), q(1, 8), q(1, 31), q(1, 32), q(1, 39), q(1, 40), q(1, 63), q(1, 64), q(1, 79), q(1, 80), q(0, 128),
+            q(1, 128), q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 2, 2, 0, 0]
+    assert q(1, 62, 1) == 0                      # f16x2 engines keep the one-CU form
+    assert q(1, 15, 0, 64) == 4 and q(1, 16, 0, 64) == 2 and q(1, 32, 0, 64) == 0   # a 64-CU device: 8 CUs per XCD
+    assert q(4096, 4096) == 0 and nb.value == 3
+    assert q(100, 100) == 0 and nb.value == 1
+    assert q(300, 300) == 0 and nb.value in (2, 3)
+    assert lib.bk_plan_query(-1, 0, 256, 0, None) == -1 and lib.bk_plan_query(1, 1, 0, 0, None) == -1
+    monkeypatch.setenv("BK_COOP", "0")
+    assert q(1, 62) == 0
