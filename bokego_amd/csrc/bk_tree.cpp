@@ -31,6 +31,7 @@ struct TNode {
     int N = 0;
     float value = 0.f;
     uint8_t has_value = 0, has_prior = 0, expanded = 0, terminal = 0;
+    uint8_t speculated = 0;  // its policy and its children's values were requested ahead of its expansion
     int kids_off = 0, n_kids = 0;
     int prior_off = -1;
     int mv = BK_NO_MOVE;
@@ -86,6 +87,8 @@ struct Game {
     int remaining = 0;
     std::vector<int> path;
     std::vector<int> req_policy, req_value;
+    std::vector<int> spec_queue;        // leaves that reached prm.speculate visits and wait for a request with room
+    std::unordered_map<int, std::vector<int>> spec_kids;   // their would-be children's node ids
     Rng rng;
     std::vector<int16_t> moves;
     std::vector<std::vector<std::pair<int16_t, int32_t>>> visit_log;  // per ply: (move, N) of the root's children
@@ -153,7 +156,49 @@ struct Game {
         return best;
     }
 
+    // Evaluate ahead (prm.speculate): request id's policy and the values of the children it would get, WITHOUT expanding
+    // it -- the children are interned (unlinked nodes) so that the later expand() finds them evaluated.
+    bool speculate(int id) {  // false: does not fit into this request (stays a candidate)
+        if (nodes[id].expanded || nodes[id].terminal || nodes[id].speculated) return true;
+        std::vector<int>& cid = spec_kids[id];   // the would-be children, interned once (a candidate may be retried)
+        if (cid.empty()) {
+            bk_pos kids[81];
+            int16_t mv[81];
+            const int n = bk_pos_children(&poses[id], kids, mv);
+            for (int i = 0; i < n; ++i) cid.push_back(intern(kids[i]));  // may reallocate `nodes`
+        }
+        auto queued = [](const std::vector<int>& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+        const bool want_p = !nodes[id].has_prior && !queued(req_policy, id);
+        int rows = want_p ? 1 : 0;
+        for (int c : cid) rows += (!nodes[c].has_value && !queued(req_value, c)) ? 1 : 0;
+        if ((int)(req_policy.size() + req_value.size()) + rows > prm.speculate_rows) return false;
+        nodes[id].speculated = 1;
+        if (want_p) req_policy.push_back(id);
+        for (int c : cid)
+            if (!nodes[c].has_value && !queued(req_value, c)) req_value.push_back(c);
+        spec_kids.erase(id);
+        return true;
+    }
+    void add_speculation() {  // a request is going out anyway: let it carry the candidates that fit, most visited first
+        std::vector<int> keep;
+        for (int id : spec_queue)
+            if (!nodes[id].expanded && !nodes[id].speculated && !nodes[id].terminal) keep.push_back(id);
+        std::stable_sort(keep.begin(), keep.end(), [&](int x, int y) { return nodes[x].N > nodes[y].N; });
+        if (keep.size() > 8) {   // candidates that never fit are retried with every request: keep the list short
+            for (size_t i = 8; i < keep.size(); ++i) spec_kids.erase(keep[i]);
+            keep.resize(8);
+        }
+        spec_queue.clear();
+        for (int id : keep)
+            if (!speculate(id)) spec_queue.push_back(id);   // does not fit this time: stays a candidate
+        if (spec_queue.empty()) spec_kids.clear();
+    }
+
     void backprop() {  // mcts.py:208-217
+        if (prm.speculate > 0) {
+            const TNode& leaf = nodes[path.back()];
+            if (!leaf.expanded && !leaf.terminal && !leaf.speculated && leaf.N + 1 == prm.speculate) spec_queue.push_back(path.back());
+        }
         double v = (double)nodes[path.back()].value;
         for (int i = (int)path.size() - 1; i >= 0; --i) {
             TNode& n = nodes[path[i]];
@@ -225,6 +270,11 @@ struct Game {
         }
         nodes.swap(nn);
         poses.swap(npos);
+        std::vector<int> nq;
+        for (int id : spec_queue)
+            if (remap[id] >= 0) nq.push_back(remap[id]);
+        spec_queue.swap(nq);
+        spec_kids.clear();
         kid_ids.swap(nk);
         priors.swap(np);
         table.clear();
@@ -257,7 +307,10 @@ struct Game {
                     expand(root);
                     if (!nodes[root].has_prior && req_policy.empty()) req_policy.push_back(root);
                     state = S_WAIT_ROOT;
-                    if (has_request()) return true;
+                    if (has_request()) {
+                        add_speculation();
+                        return true;
+                    }
                     break;
                 case S_WAIT_ROOT:
                     state = S_ROOT_READY;
@@ -297,7 +350,11 @@ struct Game {
                         backprop();
                         --remaining;
                     }
-                    if (waiting) { state = S_WAIT_LEAF; return true; }
+                    if (waiting) {
+                        add_speculation();
+                        state = S_WAIT_LEAF;
+                        return true;
+                    }
                     state = manual ? S_IDLE : S_CHOOSE;
                     break;
                 }
@@ -368,6 +425,8 @@ void bk_search_params_default(bk_search_params* p) {
     p->komi = 5.5f;
     p->record_visits = 0;
     p->prune = 0;
+    p->speculate = 0;
+    p->speculate_rows = 128;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {

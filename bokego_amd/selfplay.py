@@ -29,7 +29,8 @@ class SearchParams(ctypes.Structure):
     _fields_ = [("rollouts", ctypes.c_int32), ("expand_thresh", ctypes.c_int32), ("c_puct", ctypes.c_double),
                 ("noise_weight", ctypes.c_float), ("sample_plies", ctypes.c_int32), ("max_turns", ctypes.c_int32),
                 ("eager", ctypes.c_int32), ("komi", ctypes.c_float), ("record_visits", ctypes.c_int32),
-                ("prune", ctypes.c_int32)]
+                ("prune", ctypes.c_int32), ("speculate", ctypes.c_int32),
+                ("speculate_rows", ctypes.c_int32)]
 
 
 class GameInfo(ctypes.Structure):

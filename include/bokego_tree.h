@@ -42,6 +42,14 @@ typedef struct bk_search_params {
                               Q/N/V dicts (a position from an abandoned branch that is reached again
                               keeps its statistics); 1: drop everything outside the new root's
                               subtree at each move (bounded memory for long self-play runs)      */
+    int32_t speculate;     /* > 0: a leaf whose visit count reaches this value is marked "likely to be expanded";
+                              the next evaluation request that goes out anyway also carries that node's policy
+                              and its would-be children's values, so that its expansion -- after expand_thresh
+                              visits -- needs no round trip of its own.  The networks are pure functions and
+                              the tree is not touched: the search is the same search, rollout for rollout; only
+                              n_value_evals / n_requests differ.  0: off                                     */
+    int32_t speculate_rows; /* a request takes speculative rows only while it stays within this many rows
+                              (default 128: the range of the engine's cooperative small-batch launch)          */
 } bk_search_params;
 
 typedef struct bk_game_info {

@@ -130,3 +130,24 @@ def test_config3_on_native_tree(sds):
     dt = (time.time() - t0) / len(t["moves"])
     ev = tree.evaluator
     print(f"\nconfig3 native: {dt*1e3:.1f} ms/move, mean batch {ev.positions/ev.batches:.1f}")
+
+
+@pytest.mark.parametrize("precision,kw", [("f16x2", {}), ("f32", {"speculate": 60, "speculate_rows": 256})])
+def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
+    """search_params.speculate (the default of NativeMCTS on an f16x2 engine; forced here for fp32): likely-to-be-expanded
+    leaves are evaluated with requests that go out anyway.  BASELINE config 3 still reproduces the reference trace -- every
+    move, every root-child visit count -- with fewer requests than the plain search."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))["r1600"]
+    mk = lambda **k: NativeMCTS(Position(), nnet.HipPolicyNet(sds[0], precision=precision),  # noqa: E731
+                                nnet.HipValueNet(sds[1], precision=precision), **k)
+    ahead, plain = mk(**kw), mk(speculate=0)
+    for ref in t["moves"]:
+        for tree in (ahead, plain):
+            tree.rollout(t["rollouts"])
+            kids = {m: n for m, (n, _) in tree.child_stats().items()}
+            assert kids == {int(k): v for k, v in ref["child_N"].items()}
+            assert tree.choose().last_move == ref["move"]
+    a, p = ahead._pool.info(0), plain._pool.info(0)
+    assert a["n_requests"] < 0.8 * p["n_requests"] and a["n_value_evals"] > p["n_value_evals"]

@@ -3,6 +3,7 @@ driver and against the transcript recorded from the reference."""
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -50,3 +51,29 @@ def test_native_gtp_matches_reference_transcript():
     g.running = True
     for cmd, want in t["session"]:
         assert g.send(cmd) == want, cmd
+
+
+@pytest.mark.parametrize("prune", [0, 1])
+def test_speculative_evaluation_does_not_change_the_search(prune):
+    """search_params.speculate: leaves that reach N visits get their policy and their would-be children's values
+    evaluated with the next request that goes out anyway.  The search is the same search -- chosen moves, every root
+    child's (N, V) after every move -- with fewer requests (and more evaluations)."""
+    f = FakeNets()
+    # row by row: a BLAS matmul's bits depend on the batch's shape, and speculation changes which rows share a batch
+    # (the HIP engine's outputs do not depend on the batch: tests/test_gpu_parity.py)
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    trees = {s: NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True), expand_thresh=20, speculate=s, speculate_rows=256, prune=prune)
+             for s in (0, 8, 15)}
+    for ply in range(10):
+        stats = {}
+        for s, t in trees.items():
+            t.rollout(300)
+            stats[s] = t.child_stats()
+            t.choose()
+        assert stats[8] == stats[0] and stats[15] == stats[0], ply
+    keys = {s: t.root.key() for s, t in trees.items()}
+    assert keys[8] == keys[0] and keys[15] == keys[0]
+    info = {s: t._pool.info(0) for s, t in trees.items()}
+    assert info[8]["n_requests"] < info[0]["n_requests"] and info[15]["n_requests"] < info[0]["n_requests"]
+    assert info[8]["n_value_evals"] >= info[0]["n_value_evals"]

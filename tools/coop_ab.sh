@@ -1,9 +1,6 @@
-# the last A/B run around the cooperative launch on the GPU box (edit freely)
+# the last A/B run around the small-batch path on the GPU box (edit freely)
 cd /root/repo
 export PYTHONPATH=/root/repo
-for g in 64; do
-  for p in 1 2 3 4 1 2 3 4; do
-    s=$(timeout -k 10 200 python -m bokego_amd.selfplay --games $g --rollouts 400 --pools $p 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['seconds'], d.get('mean_batch'), d.get('batches'))")
-    echo "games $g pools $p seconds $s"
-  done
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_mcts.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 200 python tools/genmove_probe.py 40 f16x2 2>&1 | grep -v amdgpu | head -3
+timeout -k 10 200 python tools/genmove_probe.py 40 2>&1 | grep -v amdgpu | head -3

@@ -18,7 +18,12 @@ precision = sys.argv[2] if len(sys.argv) > 2 else None
 pi, val = nnet.HipPolicyNet(precision=precision), nnet.HipValueNet(precision=precision)
 pi.load_state_dict(load_bkw(os.path.join(G, "policy_19.bkw")))
 val.load_state_dict(load_bkw(os.path.join(G, "value_synth.bkw")))
-tree = NativeMCTS(mcts.Go_MCTS(), pi, val)
+kw = {}          # BK_SPECULATE / BK_SPECULATE_ROWS override NativeMCTS's defaults (on for f16x2 engines, off for fp32)
+if "BK_SPECULATE" in os.environ:
+    kw["speculate"] = int(os.environ["BK_SPECULATE"])
+if "BK_SPECULATE_ROWS" in os.environ:
+    kw["speculate_rows"] = int(os.environ["BK_SPECULATE_ROWS"])
+tree = NativeMCTS(mcts.Go_MCTS(), pi, val, **kw)
 ev = tree.evaluator
 sizes, lat = Counter(), []
 orig = ev.__class__.__call__
@@ -44,6 +49,7 @@ for _ in range(moves):
     if tree.root._terminal:
         break
 n = len(per_move)
+print("speculate =", os.environ.get("BK_SPECULATE", "(default)"), " value evals", tree._pool.info(0)["n_value_evals"], " checksum of moves", sum((i + 1) * m for i, m in enumerate(tree._pool.moves(0))))
 print(f"moves {n}  ms/move mean {1e3 * sum(per_move) / n:.3f}  min {1e3 * min(per_move):.3f}  max {1e3 * max(per_move):.3f}")
 print(f"evaluator calls {len(lat)} = {len(lat) / n:.1f} per move; in-evaluator time {1e3 * sum(lat) / n:.3f} ms/move; "
       f"per call median {1e6 * sorted(lat)[len(lat) // 2]:.0f} us  p10 {1e6 * sorted(lat)[len(lat) // 10]:.0f} us")
