@@ -78,10 +78,12 @@ class NativeMCTS:
                                                 lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1))
         self.evaluator = ev
         # Evaluation ahead of expansion (bokego_tree.h, `speculate`): same search, fewer round trips, more rows per request.
-        # It pays where a request's cost is flat in its size -- the f16x2 kernel runs <= 256 rows as one round of one-CU
-        # workgroups (1.85 -> 1.45 ms/move at 1600 rollouts) -- and loses with the fp32 kernel, whose small-batch launch gives
-        # a board 4 CUs up to 64 rows but 2 from 81 (2.2 -> 2.3..2.7 ms/move): on for f16x2 engines, off otherwise.
-        spec_default = (50, 256) if getattr(getattr(ev, "engine", None), "precision", None) == "f16x2" else (0, 128)
+        # It pays as long as the bigger request costs about the same: the f16x2 kernel runs <= 256 rows as one round of
+        # one-CU workgroups (1.85 -> 1.45 ms/move at 1600 rollouts over the first 40 moves); the fp32 kernel's small-batch
+        # launch gives a board 4 CUs up to 64 rows, 3 up to 80 but only 2 from 81, so there a request takes speculative rows
+        # only while it stays within 80 (1.91 -> 1.79 ms/move over 80-move games; with 128 or 256 rows it gets SLOWER).
+        prec = getattr(getattr(ev, "engine", None), "precision", None)
+        spec_default = (50, 256) if prec == "f16x2" else (50, 80) if prec == "f32" else (0, 128)
         prm = selfplay.search_params(rollouts=0, expand_thresh=self.expand_thresh, c_puct=self.exploration_weight,
                                      noise_weight=self.noise_weight, max_turns=MAX_TURNS, prune=kwargs.get("prune", 0),
                                      speculate=kwargs.get("speculate", spec_default[0]),
