@@ -2,9 +2,15 @@
 """bench.py -- leaf-evals/s of the fused PolicyNet+ValueNet HIP engine on MI355X.
 
 A "step" is one pass of the hot path over one batch: BASELINE.json configs[1], 4096 9x9 positions, policy
-logits + softmax + value, inputs already resident in HBM.  With --gpus N (launched through
-torch.distributed.run, one rank per GPU) every rank evaluates its own 4096 positions per step: the path shards
-with no data-path collective ("weak" scaling).
+logits + softmax + value, inputs already resident in HBM.  With --gpus N every rank (one process per GPU) evaluates
+its own 4096 positions per step: the path shards with no data-path collective ("weak" scaling).
+
+Launching.  `python3 bench.py --gpus N` starts its own N ranks: the parent makes NO GPU call, picks a free port on
+127.0.0.1, splits the host's CPUs between the ranks by the NUMA node of each rank's GPU, starts N fresh children
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the way the reference's
+bin/selfplay.py:177-199 spawns one worker per core), relays rank 0's single JSON line and returns non-zero if any child
+fails.  Under torch.distributed.run (WORLD_SIZE already set) the process is a rank, as before.  `--plan` prints the launch
+plan and exits without touching a GPU.  BK_BENCH_BACKEND=gloo BK_BENCH_DEVICE=0 rehearses the N-rank path on one card.
 
 The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the reference's arithmetic width
 (torch fp32, bokego/nnet.py:31-57,73-113) -- timed over exactly --steps launches between barriers.  Beside it:
@@ -187,6 +193,223 @@ def selfplay_cpu_baseline(cores, rollouts=400):
                       f"(batch-1 torch-CPU network calls, as the reference makes them), run concurrently"}
 
 
+# ---- the launcher: `python3 bench.py --gpus N` starts its own N ranks (no GPU call in this process) -----------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def format_cpulist(cpus):
+    cpus, parts, i = sorted(set(cpus)), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(parts)
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in HIP's enumeration order, read from sysfs only (no HIP call: the launcher must not
+    initialise the GPU): the KFD topology lists the GPUs (nodes with simd_count > 0) in the order HIP numbers them,
+    `drm_render_minor` names each one's DRM device and that device's `numa_node` is the host node its PCIe root hangs
+    off.  [] when the topology is not visible (containers without /sys/class/kfd)."""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    nodes = []
+    try:
+        for n in sorted(os.listdir(base), key=lambda v: int(v) if v.isdigit() else 1 << 30):
+            props = {}
+            try:
+                for line in open(os.path.join(base, n, "properties")):
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+            except OSError:       # a GPU this container may not open: HIP does not number it either
+                continue
+            if int(props.get("simd_count", "0") or 0) <= 0:
+                continue
+            numa = -1
+            try:
+                numa = int(open(os.path.join(sysfs, f"class/drm/renderD{int(props['drm_render_minor'])}/device/numa_node")).read())
+            except (OSError, KeyError, ValueError):
+                pass
+            nodes.append(numa)
+    except (OSError, ValueError):
+        return []
+    return nodes
+
+
+def numa_cpus(sysfs="/sys"):
+    """{numa node: [cpus]} from sysfs ({} when not visible)."""
+    base, out = os.path.join(sysfs, "devices/system/node"), {}
+    try:
+        for n in os.listdir(base):
+            if n.startswith("node") and n[4:].isdigit():
+                out[int(n[4:])] = parse_cpulist(open(os.path.join(base, n, "cpulist")).read())
+    except OSError:
+        pass
+    return out
+
+
+def smt_siblings(cpus, sysfs="/sys"):
+    """{cpu: first cpu of its physical core} for the given cpus (identity when sysfs does not say)."""
+    out = {}
+    for c in cpus:
+        try:
+            out[c] = min(parse_cpulist(open(os.path.join(sysfs, f"devices/system/cpu/cpu{c}/topology/thread_siblings_list")).read()))
+        except (OSError, ValueError):
+            out[c] = c
+    return out
+
+
+def cpu_quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        return None
+
+
+def launch_plan(n, allowed=None, gpu_nodes=None, node_cpus=None, quota=None, device=None, threads_cap=16, core_of=None):
+    """One entry per rank: the GPU it opens, the CPUs it is pinned to and the host threads it may use.
+    Ranks whose GPUs hang off the same NUMA node share that node's allowed CPUs in equal slices of whole physical
+    cores (SMT siblings stay with one rank); a GPU whose node is unknown (or has no allowed CPU) takes a slice of an
+    even split of everything allowed.  Host threads per rank
+    = min(threads_cap, slice size, cgroup CPU quota // n): the quota, not the affinity mask, is what a container owns."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    core_of = smt_siblings(allowed) if core_of is None else core_of
+    by_core = lambda cpus: sorted(cpus, key=lambda c: (core_of.get(c, c), c))  # noqa: E731
+    gpu_nodes = gpu_numa_nodes() if gpu_nodes is None else gpu_nodes
+    node_cpus = numa_cpus() if node_cpus is None else node_cpus
+    quota = cpu_quota() if quota is None else quota
+    devs = [device if device is not None else r for r in range(n)]
+    node_of = [gpu_nodes[d] if d < len(gpu_nodes) else -1 for d in devs]
+    local = {nd: [c for c in node_cpus.get(nd, []) if c in set(allowed)] for nd in set(node_of)}
+    ranks = []
+    for r in range(n):
+        nd = node_of[r]
+        peers = [q for q in range(n) if node_of[q] == nd]
+        pool = local.get(nd) or []
+        if nd < 0 or len(pool) < len(peers):
+            pool, peers, nd = allowed, list(range(n)), -1
+        pool = by_core(pool)
+        cores = sorted({core_of.get(c, c) for c in pool})
+        k = peers.index(r)
+        if len(cores) >= len(peers):       # whole cores per rank
+            mine = set(cores[k * len(cores) // len(peers):(k + 1) * len(cores) // len(peers)])
+            cpus = [c for c in pool if core_of.get(c, c) in mine]
+        else:
+            cpus = pool[k * len(pool) // len(peers):(k + 1) * len(pool) // len(peers)] or pool
+        threads = max(1, min(threads_cap, len(cpus), (quota // n) if quota else len(cpus)))
+        ranks.append({"rank": r, "local_rank": r, "device": devs[r], "numa_node": nd, "cpus": format_cpulist(cpus),
+                      "n_cpus": len(cpus), "host_threads": threads})
+    return {"world": n, "ranks": ranks, "cpus_allowed": len(allowed), "cgroup_cpu_quota": quota,
+            "gpu_numa_nodes": gpu_nodes, "numa_nodes_visible": sorted(node_cpus)}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """Parent of a self-started N-rank run.  Starts N children of this same file, relays rank 0's stdout (the one JSON
+    line), lets every child's stderr through, and returns 0 only if every child returned 0.  When a child fails the
+    others are ended by their exact PIDs (they would otherwise wait in a collective for ever)."""
+    import selectors
+    backend = os.environ.get("BK_BENCH_BACKEND", "nccl")
+    device = int(os.environ["BK_BENCH_DEVICE"]) if "BK_BENCH_DEVICE" in os.environ else None
+    plan = launch_plan(args.gpus, device=device)
+    plan.update(master_addr="127.0.0.1", master_port=free_port(), backend=backend, job=os.urandom(8).hex(),
+                argv=[a for a in argv if a != "--plan"])
+    if args.plan:
+        print(json.dumps(plan), flush=True)
+        return 0
+    procs = []
+    for r in plan["ranks"]:
+        env = dict(os.environ, RANK=str(r["rank"]), LOCAL_RANK=str(r["local_rank"]), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR=plan["master_addr"], MASTER_PORT=str(plan["master_port"]),
+                   BK_BENCH_CPUS=r["cpus"], BK_BENCH_HOST_THREADS=str(r["host_threads"]), BK_COMM_JOB=plan["job"],
+                   OMP_NUM_THREADS=str(r["host_threads"]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + plan["argv"], env=env, cwd=REPO,
+                                      stdout=subprocess.PIPE if r["rank"] == 0 else sys.stderr, text=r["rank"] == 0 or None))
+    deadline = time.time() + float(os.environ.get("BK_BENCH_LAUNCH_TIMEOUT", "1500"))
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    open_pipe, failed = True, None
+    while True:
+        if open_pipe and sel.select(timeout=0.5):
+            line = procs[0].stdout.readline()
+            if line:      # the JSON line goes to stdout; library chatter on rank 0's stdout (gloo prints there) to stderr
+                dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+                dst.write(line)
+                dst.flush()
+            else:
+                open_pipe = False
+                sel.unregister(procs[0].stdout)
+        elif not open_pipe:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed is None:
+            failed = bad[0]
+            print(f"bench.py launcher: rank {failed[0]} exited with {failed[1]}; ending the other ranks", file=sys.stderr)
+            t_end = time.time() + 10
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        if failed is None and time.time() > deadline:
+            failed = (-1, "timeout")
+            print("bench.py launcher: timeout; ending the ranks", file=sys.stderr)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        if all(c is not None for c in codes) and not open_pipe:
+            break
+        if failed is not None and all(p.poll() is not None for p in procs):
+            break
+        if failed is not None and time.time() > deadline + 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        p.wait()
+    return 0 if failed is None and all(p.returncode == 0 for p in procs) else 1
+
+
+def launch_selftest(args):
+    """What a rank does under BK_BENCH_LAUNCH_SELFTEST (tests/test_bench_cpu.py: the launcher without a GPU): join a
+    gloo group through the launcher's environment, all-reduce, rank 0 prints one line.  `fail:R` makes rank R exit 3
+    before the rendezvous, `hang:R` makes it sleep, so the parent's clean-up of the surviving ranks is under test too."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    mode, _, who = os.environ["BK_BENCH_LAUNCH_SELFTEST"].partition(":")
+    if mode == "fail" and rank == int(who):
+        return 3
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    cpus = [None] * world
+    dist.all_gather_object(cpus, format_cpulist(os.sched_getaffinity(0)))
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "collective_ranks_seen": dist.get_world_size(), "collective_backend": "gloo",
+                          "sum_of_ranks_plus_1": float(t.item()), "rank_cpus": cpus, "steps": args.steps,
+                          "host_threads": os.environ.get("BK_BENCH_HOST_THREADS")}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 # ---- GPU measurements ---------------------------------------------------------------------------------------------------
 def parity_in_run(eng, torch):
     """max |dlogit| / |dprob| / |dvalue| of THIS engine, through the timed entry point (eval_device), against the
@@ -285,7 +508,20 @@ def main():
     ap.add_argument("--no-f16x2", action="store_true", help="skip the nested f16x2 block")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
                     help="arithmetic of the HEADLINE (default f32 = the reference's width; f16x2 only for profiling that variant)")
+    ap.add_argument("--selfplay-games", type=int, default=512, help="games of the secondary configs[3] measurement (512 = the config; tests use fewer)")
+    ap.add_argument("--plan", action="store_true", help="print the N-rank launch plan (devices, CPU slices, port) and exit; no GPU call")
     args = ap.parse_args()
+
+    if args.plan or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
+        sys.exit(launch(args, sys.argv[1:]))
+    if "BK_BENCH_CPUS" in os.environ:          # a child of launch(): pin before torch starts its thread pools
+        try:
+            os.sched_setaffinity(0, parse_cpulist(os.environ["BK_BENCH_CPUS"]))
+        except OSError as e:
+            print(f"bench.py: could not pin rank to {os.environ['BK_BENCH_CPUS']}: {e}", file=sys.stderr)
+
+    if os.environ.get("BK_BENCH_LAUNCH_SELFTEST"):
+        sys.exit(launch_selftest(args))
 
     import torch
 
@@ -299,7 +535,7 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or unset WORLD_SIZE and let bench.py start them)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("BK_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
@@ -423,14 +659,16 @@ def main():
     sp = None
     if not args.no_selfplay:
         from bokego_amd import selfplay
-        threads = max(1, min(16, len(os.sched_getaffinity(0)) // world))  # host cores are shared by the ranks
-        sp = {"config": "configs[3]: 512 games, 400 rollouts/move, games sharded gid % n_gpus",
+        # host cores are shared by the ranks: a launch() child got its slice and thread count from the plan, a
+        # torch.distributed.run rank sees every CPU and takes 1/world of them (of the cgroup quota when there is one)
+        threads = int(os.environ.get("BK_BENCH_HOST_THREADS", 0)) or max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
+        sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads}
         for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
             eng.set_precision(prec)
             ev = selfplay.EngineEvaluator(eng)
             barrier()
-            local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
+            local, total = selfplay.self_play(ev, n_games=args.selfplay_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
                                               reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
             secs = reduce_max(local["seconds"])
             sp[prec] = {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
@@ -439,6 +677,7 @@ def main():
                         "first_move_hist_sum": int(sum(total["first_move_hist"]))}
         eng.set_precision(args.precision)
         sp["games_per_min"] = sp[args.precision]["games_per_min"]
+        sp["stats_allreduce_ms"] = sp[args.precision]["stats_allreduce_ms"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -469,6 +708,9 @@ def main():
             "collective_ranks_seen": dist.get_world_size() if dist is not None else 1,
             "collective_backend": (backend if dist is not None else None),
             "per_rank_leaf_evals_per_s": per_rank,
+            "launched_by": ("bench.py launcher" if "BK_BENCH_CPUS" in os.environ else
+                            "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+            "rank0_cpus": format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,
             "host_positions_e2e_pipelined_leaf_evals_per_s": e2e_pos,

@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 3
+BK_ABI_VERSION = 4
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -73,6 +73,8 @@ SYMBOLS = {
     "bk_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "bk_engine_max_batch": (ctypes.c_int, [_P]),
     "bk_plan_query": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "bk_plan_flops": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "bk_engine_synchronize": (ctypes.c_int, [_P]),
     "bk_last_error": (ctypes.c_char_p, [_P]),
 }

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 COMM_LIB_PATH = os.environ.get("BK_COMM_LIB_PATH") or os.path.join(_HERE, "libbkcomm.so")
 ID_BYTES = 128
 _VP = ctypes.c_void_p
+_T_IMPORT = time.time()   # a rank's own start, for telling a stale id file from this launch's
 
 # every symbol include/bokego_comm.h declares
 COMM_SYMBOLS = {
@@ -71,7 +72,9 @@ class NativeComm:
     @staticmethod
     def _job_tag(job):
         """16 bytes that every rank of ONE launch derives identically and another launch does not: the caller's
-        `job`, else BK_COMM_JOB, else what torch.distributed.run exports per launch (run id + master port)."""
+        `job`, else BK_COMM_JOB (bench.py's launcher exports a fresh nonce per launch), else what
+        torch.distributed.run exports (run id + master address and port).  The last one repeats across reruns with
+        the default port and no run id, which is why create() also looks at the file's age."""
         import hashlib
         if job is None:
             job = os.environ.get("BK_COMM_JOB") or "|".join(os.environ.get(k, "") for k in
@@ -79,11 +82,17 @@ class NativeComm:
         return hashlib.sha256(str(job).encode()).digest()[:16]
 
     @classmethod
-    def create(cls, rank, world, device_id, id_path, timeout=120.0, job=None):
+    def create(cls, rank, world, device_id, id_path, timeout=120.0, job=None, stale_s=None):
         """Rendezvous through a file every rank can see: rank 0 writes [job tag | id], the others wait for a file
         carrying THEIR job tag (a file left behind by another job, or by a crashed run with another tag, is
-        ignored); rank 0 removes a stale file before writing and its own file once every rank has joined."""
+        ignored); rank 0 removes a stale file before writing and its own file once every rank has joined.
+        A file with the right tag that is older than this rank's own start by more than `stale_s` seconds
+        (BK_COMM_STALE_S, default 600: ranks of one launch start within seconds of each other, but the first import of
+        torch on a fresh box can take minutes) is a crashed launch's leftover and is ignored as well, and a fresh one
+        must read the same twice 50 ms apart (rank 0 replaces a leftover as its first action)."""
         tag = cls._job_tag(job)
+        if stale_s is None:
+            stale_s = float(os.environ.get("BK_COMM_STALE_S", "600"))
         if rank == 0:
             try:
                 os.unlink(id_path)
@@ -97,12 +106,17 @@ class NativeComm:
         else:
             t0 = time.time()
             while True:
-                try:
-                    blob = open(id_path, "rb").read()
-                except FileNotFoundError:
-                    blob = b""
-                if len(blob) == 16 + ID_BYTES and blob[:16] == tag:
-                    break
+                def read():
+                    try:
+                        with open(id_path, "rb") as f:
+                            return f.read(), os.fstat(f.fileno()).st_mtime
+                    except FileNotFoundError:
+                        return b"", 0.0
+                blob, mtime = read()
+                if len(blob) == 16 + ID_BYTES and blob[:16] == tag and mtime >= _T_IMPORT - stale_s:
+                    time.sleep(0.05)
+                    if read()[0] == blob:
+                        break
                 if time.time() - t0 > timeout:
                     raise RuntimeError(f"no communicator id for this job at {id_path} after {timeout}s")
                 time.sleep(0.01)
@@ -135,3 +149,30 @@ class NativeComm:
 
     def __del__(self):
         self.close()
+
+
+def _selftest():
+    """python -m bokego_amd.comm: one rank of a world-N check of libbkcomm.so (RANK / WORLD_SIZE / LOCAL_RANK and
+    BK_COMM_ID_PATH from the environment): all-reduce of an 89-double vector and a broadcast; prints one JSON line."""
+    import json
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("BK_COMM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    t0 = time.perf_counter()
+    c = NativeComm.create(rank, world, dev, os.environ.get("BK_COMM_ID_PATH", "/tmp/bk_comm_id"))
+    t_init = time.perf_counter() - t0
+    v = (np.arange(89, dtype=np.float64) + 1) * (rank + 1)
+    out = c.allreduce_sum(v)                      # first call: includes RCCL's lazy channel set-up
+    t0 = time.perf_counter()
+    for _ in range(10):
+        out = c.allreduce_sum(v)
+    t_ar = (time.perf_counter() - t0) / 10
+    w = np.full(1_000_003, float(rank), np.float32)
+    w = c.broadcast_f32(w, root=world - 1)
+    ok = bool(np.array_equal(out, (np.arange(89) + 1) * (world * (world + 1) / 2)) and (w == world - 1).all())
+    print(json.dumps({"rank": rank, "world": c.world, "ok": ok, "init_s": t_init, "allreduce_ms": t_ar * 1e3}), flush=True)
+    c.close()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(_selftest())

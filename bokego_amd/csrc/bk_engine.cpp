@@ -263,6 +263,38 @@ void drain_events(bk_engine* e) {
     }
 }
 
+// Launch plan of the ordinary (one workgroup = 1..3 whole boards) forms: either one launch with the best single workgroup
+// size, or k whole rounds of 3-board workgroups (one per CU) followed by a tail launch whose workgroup size makes the
+// partial last round shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead
+// of 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.  A pure function
+// of its arguments (and BK_FORCE_NB / BK_NO_SPLIT): enqueue() launches by it, bk_plan_flops() prices it.
+struct LaunchPlan {
+    int nb1;                       // single launch: boards per workgroup
+    int head_p, head_v, tail_nb;   // tail_nb != 0: head_p + head_v 3-board workgroups first, the rest as tail_nb-board ones
+};
+LaunchPlan plan_launch(int B_policy, int B_value, int n_cu, int precision) {
+    LaunchPlan pl{bk_pick_nb(B_policy, B_value, n_cu, precision), 0, 0, 0};
+    const long single = bk_launch_cost(B_policy, B_value, pl.nb1, n_cu, precision);
+    long best = single;
+    const int full_p = B_policy / 3, full_v = B_value / 3;   // complete 3-board workgroups per net
+    if (!getenv("BK_FORCE_NB") && !getenv("BK_NO_SPLIT")) {
+        for (long k = 1; k * n_cu <= full_p + full_v; ++k) {
+            const long head = k * n_cu;
+            int hp = (int)std::min<long>(full_p, (head * full_p / (full_p + full_v)) & ~3L);  // keep the 4-block XCD pairing
+            int hv = (int)(head - hp);
+            if (hv > full_v) { hv = full_v; hp = (int)(head - hv); }
+            const int rp = B_policy - 3 * hp, rv = B_value - 3 * hv;
+            if (rp + rv == 0) break;
+            const int nbt = bk_pick_nb(rp, rv, n_cu, precision);
+            const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, n_cu, precision) + (precision == BK_PRECISION_F16X2 ? 4 : 1);  // + a second launch's overhead
+            // worth it from 3 % (f16x2: power-limited, the idle CUs of a ragged last round let the busy ones clock higher)
+            // resp. 1 % (fp32: issue-limited at full clock, a shorter last round is a shorter launch)
+            if (cost < best && cost * 100 <= single * (precision == BK_PRECISION_F16X2 ? 97 : 99)) { best = cost; pl.head_p = hp; pl.head_v = hv; pl.tail_nb = nbt; }
+        }
+    }
+    return pl;
+}
+
 // enqueue one kernel launch on `stream`; all pointers are device pointers
 // d_flag/tag: where and with what value the f16x2 kernel reports an activation outside the fp16 range.
 // gated_redo (device-pointer path, f16x2): the exact-fp32 kernel follows on the same stream with the same launch plan,
@@ -332,30 +364,8 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
         return BK_OK;
     }
-    // Launch plan: either one launch with the best single workgroup size, or k whole rounds of 3-board
-    // workgroups (one per CU) followed by a tail launch whose workgroup size makes the partial last round
-    // shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead of
-    // 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.
-    const int nb1 = bk_pick_nb(a.B_policy, a.B_value, e->n_cu, precision);
-    const long single = bk_launch_cost(a.B_policy, a.B_value, nb1, e->n_cu, precision);
-    long best = single;
-    int head_p = 0, head_v = 0, tail_nb = 0;
-    const int full_p = a.B_policy / 3, full_v = a.B_value / 3;   // complete 3-board workgroups per net
-    if (!getenv("BK_FORCE_NB") && !getenv("BK_NO_SPLIT")) {
-        for (long k = 1; k * e->n_cu <= full_p + full_v; ++k) {
-            const long head = k * e->n_cu;
-            int hp = (int)std::min<long>(full_p, (head * full_p / (full_p + full_v)) & ~3L);  // keep the 4-block XCD pairing
-            int hv = (int)(head - hp);
-            if (hv > full_v) { hv = full_v; hp = (int)(head - hv); }
-            const int rp = a.B_policy - 3 * hp, rv = a.B_value - 3 * hv;
-            if (rp + rv == 0) break;
-            const int nbt = bk_pick_nb(rp, rv, e->n_cu, precision);
-            const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, e->n_cu, precision) + (precision == BK_PRECISION_F16X2 ? 4 : 1);  // + a second launch's overhead
-            // worth it from 3 % (f16x2: power-limited, the idle CUs of a ragged last round let the busy ones clock higher)
-            // resp. 1 % (fp32: issue-limited at full clock, a shorter last round is a shorter launch)
-            if (cost < best && cost * 100 <= single * (precision == BK_PRECISION_F16X2 ? 97 : 99)) { best = cost; head_p = hp; head_v = hv; tail_nb = nbt; }
-        }
-    }
+    const LaunchPlan pl = plan_launch(a.B_policy, a.B_value, e->n_cu, precision);
+    const int nb1 = pl.nb1, head_p = pl.head_p, head_v = pl.head_v, tail_nb = pl.tail_nb;
     if (tail_nb) {
         bk_eval_args h = a;
         h.B_policy = 3 * head_p;
@@ -744,6 +754,36 @@ int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int* board
     if (n_policy < 0 || n_value < 0 || n_cu <= 0 || (precision != BK_PRECISION_F32 && precision != BK_PRECISION_F16X2)) return BK_ERR_ARG;
     if (boards_per_workgroup) *boards_per_workgroup = bk_pick_nb(n_policy, n_value, n_cu, precision);
     return precision == BK_PRECISION_F32 ? bk_coop_slices(n_policy + n_value, n_cu) : 0;
+}
+
+int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* executed_mfma_flop, double* algorithmic_flop,
+                  int* n_launches) {
+    if (n_policy < 0 || n_value < 0 || n_cu <= 0) return BK_ERR_ARG;
+    // valid-tap multiply-adds of one position, PolicyNet (trunk + 1x1 head) and ValueNet (+ the 81-64-1 MLP)
+    const double alg = 2.0 * (66706944.0 * n_policy + 66712192.0 * n_value);
+    double exe = 0.0;
+    int launches = 0;
+    if (n_policy + n_value > 0) {
+        if (cooperative && bk_coop_slices(n_policy + n_value, n_cu)) {
+            exe = bk_mfma_flop_per_workgroup(1) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
+            launches = 1;
+        } else {
+            const LaunchPlan pl = plan_launch(n_policy, n_value, n_cu, BK_PRECISION_F32);
+            auto wgs = [](int b, int nb) { return (double)((b + nb - 1) / nb); };
+            if (pl.tail_nb) {
+                exe = bk_mfma_flop_per_workgroup(3) * (pl.head_p + pl.head_v) +
+                      bk_mfma_flop_per_workgroup(pl.tail_nb) * (wgs(n_policy - 3 * pl.head_p, pl.tail_nb) + wgs(n_value - 3 * pl.head_v, pl.tail_nb));
+                launches = 2;
+            } else {
+                exe = bk_mfma_flop_per_workgroup(pl.nb1) * (wgs(n_policy, pl.nb1) + wgs(n_value, pl.nb1));
+                launches = 1;
+            }
+        }
+    }
+    if (executed_mfma_flop) *executed_mfma_flop = exe;
+    if (algorithmic_flop) *algorithmic_flop = alg;
+    if (n_launches) *n_launches = launches;
+    return BK_OK;
 }
 
 #ifdef BK_STAMPS

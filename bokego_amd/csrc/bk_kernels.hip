@@ -790,7 +790,34 @@ hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- executed work, counted from the tile tables the kernels run on (bk_plan_flops, bench.py) ----------------------------
+// (tile, tap) pairs one position group of a workgroup executes in a kw x kw layer: interior tiles run every tap, an edge
+// tile skips the kw * (kw/2) taps that point off the board on its side -- exactly the branches of conv_layer::do_group.
+template <class F>
+constexpr long tile_taps(int kw) {
+    const int taps = kw * kw, skip = kw * (kw / 2);
+    const int nx = (F::X0 >= 0) + (F::X1 >= 0);
+    const int ny = (F::Y0a >= 0 ? F::Y0b - F::Y0a : 0) + (F::Y1 >= 0);
+    return (long)(F::A1 - F::A0) * taps + (long)(nx + ny) * (taps - skip);
+}
+static_assert(tile_taps<Tiles<3>>(3) == 63 && tile_taps<Tiles<3>>(5) == 170, "3 boards: 63 of 72 / 170 of 200 tile-taps");
+static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 54, "2 boards: 87 of 99; 1 board: all 54");
+// FLOP the matrix unit executes for ONE net on one NB-board workgroup: per (tile, tap) 7 k-steps in layer 0 (28 input
+// slots) resp. 32 in a 3x3 layer, x 8 cout tiles, of v_mfma_f32_16x16x4_f32 (2 * 16 * 16 * 4 = 2,048 FLOP each)
+template <int NB>
+constexpr double mfma_flop_workgroup() {
+    using F = Tiles<NB>;
+    return 2048.0 * 8 * F::WM * (double)(tile_taps<F>(5) * 7 + 6 * tile_taps<F>(3) * 32);
+}
+// the cooperative form deals the one-board tile set (6 position tiles x 8 cout tiles, no edge classes) out to its slices
+static_assert(CoopTiles<4, 1, 2>::X0 < 0 && CoopTiles<4, 1, 2>::Y0a < 0 && CoopTiles<1, 3, 1>::ROWT * 3 == Tiles<1>::RT, "coop = 1-board tiles");
+
 }  // namespace
+
+double bk_mfma_flop_per_workgroup(int nb) {
+    return nb == 3 ? mfma_flop_workgroup<3>() : nb == 2 ? mfma_flop_workgroup<2>() : mfma_flop_workgroup<1>();
+}
+
 
 // Picks boards-per-workgroup.  A CU's matrix pipes are the bound, so the cost of a choice is (workgroup rounds over
 // the CUs) x (time of one round of nb-board workgroups, one per CU).  NB=1 workgroups are small enough to sit two per

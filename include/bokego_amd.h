@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 3
+#define BK_ABI_VERSION 4
 
 typedef enum bk_status {
     BK_OK = 0,
@@ -163,8 +163,8 @@ int bk_encode_positions(bk_engine *e, const void *positions, int B, uint8_t *pla
 
 /*
  * Arithmetic of the conv stacks (new; the reference computes in torch fp32, nnet.py:31-57,73-113):
- *   BK_PRECISION_FP32   (default) v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation -- the
- *                       reference's arithmetic width
+ *   BK_PRECISION_FP32   (default) v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (bit-identical to
+ *                       an fmaf chain) -- the reference's arithmetic width
  *   BK_PRECISION_F16X2  opt-in: every operand split into an fp16 hi/lo pair (22 significant bits), three
  *                       v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation; measured as close to a float64
  *                       evaluation of the reference as the fp32 kernel is, ~4x the throughput.
@@ -192,6 +192,17 @@ int bk_engine_max_batch(bk_engine *e);
  * *boards_per_workgroup (may be NULL) receives the ordinary form's workgroup size (1..3) for a single launch.
  */
 int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int *boards_per_workgroup);
+/*
+ * What the fp32 kernel's matrix unit executes for such a request, counted from the tile tables the kernel is compiled
+ * from (bk_kernels.hip, Tiles<NB>: 16-position tiles x taps that are not skipped x k-steps x cout tiles x 2,048 FLOP per
+ * v_mfma_f32_16x16x4_f32), over the launch plan the engine would use (a single launch, k rounds of 3-board workgroups +
+ * a tail, or -- cooperative != 0 and a small request -- the cooperative form), and the algorithmic work beside it
+ * (valid taps only: 2 x 66,706,944 FLOP per PolicyNet row, 2 x 66,712,192 per ValueNet row).  The quotient
+ * is what separates MFMA-pipe occupancy from the roofline fraction bench.py reports: padding rows (243 -> 256), edge taps
+ * inside mixed tiles, the 27 -> 28 channel pad of layer 0.  Pure function, no GPU.  Any out pointer may be NULL.
+ */
+int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double *executed_mfma_flop,
+                  double *algorithmic_flop, int *n_launches);
 int bk_engine_synchronize(bk_engine *e);
 const char *bk_last_error(bk_engine *e); /* e == NULL: last error of a failed create */
 

@@ -1,4 +1,5 @@
 """bench.py's CPU legs (the reference-CPU baselines) run without a GPU: keeps them from rotting between GPU runs."""
+import json
 import os
 import sys
 
@@ -26,3 +27,75 @@ def test_cpu_baseline_legs_on_a_small_sample():
     assert cpu["timed_output_vs_oracle_sample"]["max_abs_dlogit_vs_oracle"] == 0.0
     sp = bench.selfplay_cpu_baseline(2, rollouts=30)
     assert sp["games"] == 2 and sp["games_per_min"] > 0 and 40 <= sp["mean_plies"] <= 90
+
+
+# ---- the launcher: `python3 bench.py --gpus N` starts its own ranks -------------------------------
+def _run_bench(args, env=None, timeout=180):
+    import subprocess
+    e = dict(os.environ, **(env or {}))
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                          cwd=REPO, env=e)
+
+
+def test_cpulist_round_trip():
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert bench.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == "0-3,8,10-11"
+    assert bench.parse_cpulist("") == []
+
+
+def test_launch_plan_splits_whole_cores_by_numa_node():
+    """An 8-GPU node as the pool describes it: 2 sockets x 64 cores x 2 threads, four GPUs per socket, a 128-CPU quota."""
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    plan = bench.launch_plan(8, allowed=range(256), gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], node_cpus=node_cpus, quota=128,
+                             core_of={c: c % 128 for c in range(256)})
+    seen = set()
+    for r in plan["ranks"]:
+        cpus = bench.parse_cpulist(r["cpus"])
+        assert len(cpus) == 32 and r["host_threads"] == 16 and r["device"] == r["rank"] == r["local_rank"]
+        assert set(cpus) <= set(node_cpus[r["numa_node"]]) and r["numa_node"] == (0 if r["rank"] < 4 else 1)
+        assert {c % 128 for c in cpus} == {c % 128 for c in cpus if c < 128}, "SMT siblings stay with one rank"
+        assert not seen & set(cpus)
+        seen |= set(cpus)
+    assert len(seen) == 256
+    # topology not visible (this container): an even split of what the process may run on, nothing lost, nothing shared
+    flat = bench.launch_plan(3, allowed=range(8), gpu_nodes=[], node_cpus={}, quota=None, core_of={})
+    assert [r["cpus"] for r in flat["ranks"]] == ["0-1", "2-4", "5-7"]
+    # one-GPU rehearsal: every rank opens the same device; the quota bounds the threads
+    reh = bench.launch_plan(2, allowed=range(256), gpu_nodes=[1], node_cpus=node_cpus, quota=16, device=0,
+                            core_of={c: c % 128 for c in range(256)})
+    assert [r["device"] for r in reh["ranks"]] == [0, 0] and [r["host_threads"] for r in reh["ranks"]] == [8, 8]
+    assert all(r["numa_node"] == 1 for r in reh["ranks"])
+
+
+def test_plan_flag_prints_the_plan_and_starts_nothing():
+    out = _run_bench(["--gpus", "4", "--steps", "3", "--plan"])
+    assert out.returncode == 0, out.stderr[-1000:]
+    plan = json.loads(out.stdout)
+    assert plan["world"] == 4 and len(plan["ranks"]) == 4 and plan["master_addr"] == "127.0.0.1" and plan["master_port"] > 0
+    assert plan["argv"] == ["--gpus", "4", "--steps", "3"] and plan["backend"] == "nccl"
+    every = [c for r in plan["ranks"] for c in bench.parse_cpulist(r["cpus"])]
+    assert sorted(every) == sorted(os.sched_getaffinity(0))
+
+
+def test_launcher_starts_n_ranks_and_relays_one_line():
+    """The launcher end to end without a GPU: N children rendezvous through the environment it gave them (gloo), each
+    pinned to its own CPU slice; the parent prints rank 0's line and nothing else on stdout."""
+    out = _run_bench(["--gpus", "3", "--steps", "7"], env={"BK_BENCH_LAUNCH_SELFTEST": "1"})
+    assert out.returncode == 0, out.stderr[-1000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["collective_ranks_seen"] == 3 and d["sum_of_ranks_plus_1"] == 6.0 and d["steps"] == 7
+    cpus = [set(bench.parse_cpulist(c)) for c in d["rank_cpus"]]
+    if len(os.sched_getaffinity(0)) >= 3:
+        assert not (cpus[0] & cpus[1]) and not (cpus[1] & cpus[2]) and set().union(*cpus) == set(os.sched_getaffinity(0))
+
+
+def test_launcher_returns_nonzero_and_ends_the_others_when_a_rank_fails():
+    import time
+    t0 = time.time()
+    out = _run_bench(["--gpus", "2"], env={"BK_BENCH_LAUNCH_SELFTEST": "fail:1", "BK_BENCH_LAUNCH_TIMEOUT": "60"})
+    assert out.returncode == 1 and "rank 1 exited with 3" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.strip()] and time.time() - t0 < 60

@@ -38,3 +38,30 @@ def test_bench_line_contract():
     assert f16["roofline"]["peak"] == 2500.0 and f16["value"] > d["value"]
     sb = d["small_batch_latency"]
     assert sb["B62"]["cooperative_us"] < 0.6 * sb["B62"]["one_cu_per_board_us"] and sb["B62"]["fallbacks"] == 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no torch.distributed.run around it: the parent starts two
+    fresh ranks and relays one line.  On a one-GPU box the two ranks share the card and meet over gloo (RCCL refuses two
+    ranks on one device), which exercises everything except RCCL itself; with two GPUs it is the real thing."""
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    real = torch.cuda.device_count() >= 2
+    if not real:
+        env.update(BK_BENCH_BACKEND="gloo", BK_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--sustain", "0",
+                          "--no-f16x2", "--selfplay-games", "32"], capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective_ranks_seen"] == 2 and d["collective_backend"] == ("nccl" if real else "gloo")
+    assert len(d["per_rank_leaf_evals_per_s"]) == 2 and all(v > 1e4 for v in d["per_rank_leaf_evals_per_s"])
+    assert d["launched_by"] == "bench.py launcher" and d["cpu_baseline"] is None
+    sp = d["selfplay"]
+    assert sp["f32"]["games"] == 32 and sp["games_per_min"] > 0 and sp["stats_allreduce_ms"] > 0
+    assert sp["f32"]["first_move_hist_sum"] == 32
+    B = d["config"]["batch_per_gpu"]
+    assert abs(d["value"] - 2 * B * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

@@ -77,3 +77,64 @@ def test_native_c_self_play_driver():
     _, total = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=24, rollouts=100, cap=8192)
     assert total["plies"] == runs[0]["plies"]
     assert abs(total["value_evals"] - runs[0]["value_evals"]) <= 0.01 * total["value_evals"]
+
+
+# ---- more than one rank: these need two GPUs and skip themselves on the one-GPU box ----------------
+def _two_gpus():
+    return torch.cuda.device_count() >= 2   # counting devices does not initialise the GPU on this image
+
+
+def _spawn_ranks(argv, world, extra_env, timeout=300):
+    """`world` fresh processes of `argv`, one per GPU, with the torch.distributed.run environment; -> their stdouts."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONPATH=REPO, **extra_env)
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        outs.append(o)
+    return outs
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_native_comm_world2(tmp_path):
+    """libbkcomm.so between two ranks on two GPUs: RCCL all-reduce + broadcast over xGMI, id through the file rendezvous."""
+    import json
+    outs = _spawn_ranks(["-m", "bokego_amd.comm"], 2, {"BK_COMM_ID_PATH": str(tmp_path / "id"), "BK_COMM_JOB": "t-native-2"})
+    res = [json.loads(o.strip().splitlines()[-1]) for o in outs]
+    assert [r["rank"] for r in res] == [0, 1] and all(r["ok"] and r["world"] == 2 for r in res)
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_torch_distributed_nccl_world2_self_play_shards():
+    """bokego_amd.selfplay as two ranks over torch.distributed's nccl (= RCCL) backend: the reduced statistics of a
+    small generation equal the one-rank run's."""
+    import json
+    import os
+    from bokego_amd import selfplay
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    from conftest import GOLDEN
+    outs = _spawn_ranks(["-m", "bokego_amd.selfplay", "--games", "16", "--rollouts", "60", "--max-turns", "30"], 2, {})
+    two = json.loads(outs[0].strip().splitlines()[-1])
+    eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=8192)
+    _, one = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=16, rollouts=60, max_turns=30, cap=8192)
+    eng.close()
+    assert two["n_gpus"] == 2 and two["games"] == 16 == one["games"] and two["plies"] == one["plies"]
+    assert two["black_wins"] == one["black_wins"] and two["leaf_evals"] == one["value_evals"]
