@@ -63,18 +63,45 @@ def make_workload(B, rank):
     return make_batch(B, seed_base=20260 + rank * B, dtype=np.float32, with_records=True)
 
 
-def measured_traffic(batch, precision):
-    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary of this kernel
-    (profiles/*_pmc_<precision>.json, produced by tools/profile_bench.sh + tools/summarize_prof.py).  Read from a
-    file, so it describes the commit that file was made at, not this run: the source is named beside it."""
+def measured_counters(batch, precision):
+    """What the newest committed rocprofv3 PMC summary of this kernel says (profiles/*_pmc_<precision>.json, produced by
+    tools/profile_bench.sh + tools/summarize_prof.py): HBM-side bytes per launch, MFMA-pipe occupancy, effective clock and
+    the FLOP the matrix unit executed per workgroup.  Read from a file, so it describes the commit that file was made at,
+    not this run: every figure carries `source`."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_pmc_{precision}.json")))
     if not files:
-        return None, None
+        return None
     d = json.load(open(files[-1]))
     if d.get("batch") != batch:
-        return None, None
-    return d.get("hbm_traffic_bytes_per_launch"), f"from_file:profiles/{os.path.basename(files[-1])} (batch {d.get('batch')})"
+        return None
+    c = d.get("counters", {})
+    out = {"source": f"from_file:profiles/{os.path.basename(files[-1])} (batch {d.get('batch')})",
+           "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
+           "mfma_busy": d.get("mfma_busy"), "effective_clock_ghz": d.get("effective_clock_ghz")}
+    if out["mfma_busy"] is None and c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)      # 1,024 SIMDs, 8 XCDs
+    if precision == "f32" and c.get("SQ_INSTS_VALU_MFMA_MOPS_F32") and c.get("SQ_WAVES"):
+        # the counter ticks once per 512 FLOP; 8 waves per workgroup.  Per workgroup, so that launches of other sizes in
+        # the profiled run (the parity check's 536 positions) do not dilute it
+        out["executed_mfma_flop_per_workgroup"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / (c["SQ_WAVES"] / 8)
+    return out
+
+
+def executed_over_algorithmic(batch, n_cu=256):
+    """fp32 kernel: FLOP the matrix unit executes / algorithmic FLOP for one launch of `batch` positions on both nets,
+    from the tile tables the kernel is compiled from (C ABI bk_plan_flops: tiles x taps not skipped x k-steps x 2,048
+    FLOP per v_mfma_f32_16x16x4_f32, over the engine's launch plan).  Also the 3-board workgroup's own figure."""
+    import ctypes
+    from bokego_amd import _lib
+    lib = _lib.load()
+    ex, al, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    if lib.bk_plan_flops(batch, batch, n_cu, 0, ctypes.byref(ex), ctypes.byref(al), ctypes.byref(nl)):
+        return None
+    wg3 = ctypes.c_double()
+    lib.bk_plan_flops(3 * n_cu, 0, n_cu, 0, ctypes.byref(wg3), None, None)     # one full round of 3-board workgroups
+    return {"ratio": ex.value / al.value, "executed_mfma_flop_per_launch": ex.value, "launches_per_step": nl.value,
+            "executed_mfma_flop_per_3_board_workgroup": wg3.value / n_cu, "source": "bk_plan_flops (tile tables of the compiled kernel)"}
 
 
 # ---- host CPU description -------------------------------------------------------------------------------------------
@@ -478,14 +505,28 @@ def roofline(precision, batch, kern_ms, sust, spread):
     f16 = precision == "f16x2"
     peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
     achieved = batch * FLOP_PER_LEAF / (kern_ms * 1e-3) / 1e12
-    traffic, src = measured_traffic(batch, precision)
+    pmc = measured_counters(batch, precision) or {}
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-         "traffic": traffic, "traffic_source": src, "kernel": KERNEL[precision], "kernel_ms": kern_ms,
-         "kernel_ms_isolated_p10_p50_p90": spread,
+         "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "traffic_source": pmc.get("source"), "kernel": KERNEL[precision],
+         "kernel_ms": kern_ms, "kernel_ms_isolated_p10_p50_p90": spread,
          "algorithmic_flop_per_launch": batch * FLOP_PER_LEAF, "algorithmic_hbm_bytes_per_launch": batch * BYTES_PER_LEAF,
-         # f16x2 executes 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC; both variants issue the dense
-         # padded work minus the zero-halo taps they skip
-         "executed_mfma_flop_per_algorithmic_flop": 3.0 if f16 else 1.0}
+         "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"), "pmc_source": pmc.get("source")}
+    if f16:
+        # nominal: 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC, before padding and skipped zero-halo taps
+        # (executed_mfma_tflops below is the counted figure for 3-board workgroups)
+        r["executed_mfma_flop_per_algorithmic_flop"] = 3.0
+        r["executed_ratio_source"] = "nominal (3 products per MAC)"
+    else:
+        ex = executed_over_algorithmic(batch)
+        r["executed_mfma_flop_per_algorithmic_flop"] = ex["ratio"] if ex else None
+        r["executed_ratio_source"] = ex["source"] if ex else None
+        if ex:
+            r["executed_mfma_flop_per_launch"] = ex["executed_mfma_flop_per_launch"]
+            r["executed_mfma_tflops"] = ex["executed_mfma_flop_per_launch"] / (kern_ms * 1e-3) / 1e12
+            r["executed_frac_of_peak"] = r["executed_mfma_tflops"] / peak
+            if pmc.get("executed_mfma_flop_per_workgroup"):     # the counters' view of the same number, per 3-board workgroup
+                r["pmc_executed_mfma_flop_per_workgroup"] = pmc["executed_mfma_flop_per_workgroup"]
+                r["tile_table_mfma_flop_per_3_board_workgroup"] = ex["executed_mfma_flop_per_3_board_workgroup"]
     if sust:
         r["sustained_kernel_ms"] = sust["kernel_ms"]
         r["sustained_frac"] = batch * FLOP_PER_LEAF / (sust["kernel_ms"] * 1e-3) / 1e12 / peak

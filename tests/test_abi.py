@@ -33,7 +33,27 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, f), f"{f} declared in include/bokego_amd.h but not exported"
         assert f in _lib.SYMBOLS, f"{f} has no ctypes prototype in bokego_amd/_lib.py"
     assert set(_lib.SYMBOLS) == set(fns)
-    assert lib.bk_abi_version() == 3
+    assert lib.bk_abi_version() == 4
+
+
+def test_plan_flops_counts_the_tile_tables(lib):
+    """bk_plan_flops (no GPU): executed fp32-MFMA FLOP of a request from the compiled kernel's tile tables, against the
+    algorithmic FLOP of SURVEY 8d.  The 3-board figure is the one the rocprofv3 counters give per workgroup
+    (profiles/r02_pmc_f32.json: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / (SQ_WAVES / 8) = 435,355,648)."""
+    def q(p, v, coop=0):
+        ex, al, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        assert lib.bk_plan_flops(p, v, 256, coop, ctypes.byref(ex), ctypes.byref(al), ctypes.byref(nl)) == 0
+        return ex.value, al.value, nl.value
+    ex, al, nl = q(768, 0)                                  # one round of 3-board workgroups, PolicyNet only
+    assert nl == 1 and ex / 256 == 2048 * 8 * 2 * (170 * 7 + 6 * 63 * 32) == 435355648 and al == 768 * 2 * 66706944
+    ex, al, nl = q(4096, 4096)                              # the bench step: 10 rounds of 3-board workgroups + a 2-board tail
+    assert nl == 2 and al == 4096 * 266838272
+    assert ex == 2560 * 435355648 + 256 * 2048 * 8 * (235 * 7 + 6 * 87 * 32)
+    assert 1.05 < ex / al < 1.10
+    one = 2048 * 8 * 6 * (25 * 7 + 6 * 9 * 32)              # a single board: 6 tiles, every tap
+    assert q(1, 62, coop=1) == (63 * one, 2.0 * (66706944 + 62 * 66712192), 1) == q(1, 62, coop=0)
+    assert q(0, 0) == (0.0, 0.0, 0) and lib.bk_plan_flops(-1, 0, 256, 0, None, None, None) == -1
+    assert lib.bk_plan_flops(5, 5, 256, 0, None, None, None) == 0   # every out pointer may be NULL
 
 
 def test_struct_layout_matches_header():

@@ -32,6 +32,12 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.01
+    # what the matrix unit executes per algorithmic FLOP: counted from the kernel's tile tables, not asserted
+    assert 1.05 < r["executed_mfma_flop_per_algorithmic_flop"] < 1.10 and "tile tables" in r["executed_ratio_source"]
+    assert abs(r["executed_frac_of_peak"] - r["frac"] * r["executed_mfma_flop_per_algorithmic_flop"]) < 1e-9
+    if r.get("pmc_executed_mfma_flop_per_workgroup"):      # the committed PMC pass counted the same work per workgroup
+        assert abs(r["pmc_executed_mfma_flop_per_workgroup"] / r["tile_table_mfma_flop_per_3_board_workgroup"] - 1) < 0.01
+    assert r["mfma_busy"] is None or 0.8 < r["mfma_busy"] <= 1.0
     par = d["config"]["parity"]
     assert par["max_abs_dlogit"] < 1e-4 and par["max_abs_dprob"] < 1e-5 and par["max_abs_dvalue"] < 1e-4
     f16 = d["f16x2"]

@@ -67,8 +67,12 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
         pmc, meta = collections.OrderedDict(), {}
         for f in sorted(glob.glob(os.path.join(src, f"pmc_{prec}_*", "*", "*_counter_collection.csv"))):
             agg = collections.defaultdict(list)
-            for r in csv.DictReader(open(f)):
-                if kname in r["Kernel_Name"]:
+            recs = [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
+            # the profiled run also launches this kernel on other batch sizes (the in-run parity check's 536 positions):
+            # keep the dispatches of the most frequent grid only, so that every mean is per launch of the timed batch
+            grid = collections.Counter(r["Grid_Size"] for r in recs).most_common(1)[0][0] if recs else None
+            for r in recs:
+                if r["Grid_Size"] == grid:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
             for k, v in agg.items():
@@ -79,11 +83,22 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
         for k, (m, n) in pmc.items():
             o.write(f"| {k} | {m:.6g} | {n} |\n")
         g = pmc.get("GRBM_GUI_ACTIVE", (0, 0))[0]
+        derived = {}
         if g:
+            derived["effective_clock_ghz"] = g / 8 / (own_ms * 1e-3) / 1e9
             o.write(f"\nEffective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time ({own_ms:.4f} ms) = {g/8/(own_ms*1e-3)/1e9:.3f} GHz\n")
         mf = pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0]
         if mf and g:
+            derived["mfma_busy"] = mf / 1024 / (g / 8)
             o.write(f"MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE/8) = {mf/1024/(g/8)*100:.1f} %\n")
+        mops, waves = pmc.get("SQ_INSTS_VALU_MFMA_MOPS_F32", (0, 0))[0], pmc.get("SQ_WAVES", (0, 0))[0]
+        if mops and waves:
+            wgs = waves / (int(meta["Workgroup_Size"]) / 64)
+            derived["executed_mfma_flop_per_launch"] = mops * 512
+            derived["executed_mfma_flop_per_workgroup"] = mops * 512 / wgs
+            o.write(f"Executed fp32-MFMA work = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = {mops*512/1e12:.4f} TFLOP per launch of {wgs:.0f} workgroups "
+                    f"= {mops*512/wgs/1e6:.2f} MFLOP per workgroup (tile tables, bk_plan_flops: 435.36 per 3-board workgroup and net); "
+                    f"algorithmic for the {wgs*3:.0f} boards of this launch {wgs*3*133419136/1e12:.4f} TFLOP: executed / algorithmic = {mops*512/(wgs*3*133419136):.4f}\n")
         fs, ws = pmc.get("FETCH_SIZE", (0, 0))[0], pmc.get("WRITE_SIZE", (0, 0))[0]
         traffic = (2 * fs + ws) * 1024 if fs else None
         if fs:
@@ -98,6 +113,7 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
         if a and g:
             o.write(f"LDS: bank-conflict cycles / active cycles = {c/a*100:.1f} %; LDS active = {a/256/(g/8)*100:.1f} % of CU time\n")
         json.dump({"tag": tag, "precision": prec, "kernel": kern["Name"], "rocprof_avg_kernel_ms": avg_ms, "batch": B,
+                   "own_kernel_ms": own_ms, "dispatch": meta, **derived,
                    "counters": {k: v[0] for k, v in pmc.items()}, "hbm_traffic_bytes_per_launch": traffic,
                    "traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction"},
                   open(os.path.join(dst, f"{tag}_pmc_{prec}.json"), "w"), indent=1)
