@@ -484,7 +484,7 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->dev_allocs.push_back(e->d_dev_flag);
     TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
     {
-        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE * sizeof(unsigned int);
+        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
         e->dev_allocs.push_back(e->d_coop_xchg);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_sync, sb));
@@ -643,10 +643,12 @@ int bk_wait(bk_engine* e, int64_t ticket) {
         if (s.B > 0 && (hf[0] || hf[1])) {
             // word 0: the f16x2 kernel clamped an activation -- redo this request on the exact fp32 kernel;
             // word 1: a workgroup of the cooperative launch gave up waiting for its peers -- redo with one CU per board
-            // (the arrival counters are left anywhere: clear them)
+            // (the arrival counters are left anywhere and the engine's poison word is up: clear both, in stream order.
+            // Cooperative requests that were queued behind the failed one ran before this memset: they saw the poison
+            // word, raised their own word 1 and are redone here as well when their turn to be waited for comes)
             if (hf[1]) {
                 e->st.coop_fallbacks += 1;
-                HIP_TRY(e, hipMemsetAsync(e->d_coop_sync, 0, (size_t)BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE * sizeof(unsigned int), e->stream));
+                HIP_TRY(e, hipMemsetAsync(e->d_coop_sync, 0, (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int), e->stream));  // counters + poison word
             } else {
                 e->st.f16_overflow_fallbacks += 1;
             }

@@ -86,6 +86,12 @@ hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream
 double bk_mfma_flop_per_workgroup(int nb);   // fp32 kernel: executed MFMA FLOP of one net on one nb-board workgroup (tile tables)
 #define BK_COOP_MAX_TASKS 128
 #define BK_COOP_SYNC_STRIDE 64   // unsigned ints between two tasks' arrival counters
+// behind the counters: the engine's POISON word.  A cooperative workgroup that gives up waiting raises it (beside its own
+// request's coop_err); until the host has cleared it together with the counters (bk_wait of the failed ticket, stream-ordered)
+// every cooperative launch that was already queued behind the failed one sees it at entry, raises ITS request's coop_err and
+// runs through without waiting for anybody: the counters it would meet at are not trustworthy, and its outputs are redone too.
+#define BK_COOP_POISON_WORD (BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE)
+#define BK_COOP_SYNC_WORDS (BK_COOP_POISON_WORD + BK_COOP_SYNC_STRIDE)
 int bk_coop_slices(int tasks, int n_cu);   // 0: not a cooperative case
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

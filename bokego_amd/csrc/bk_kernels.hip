@@ -595,7 +595,9 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
 //   * the poll is BOUNDED (COOP_SPIN_LIMIT polls, ~50 ms): if the peers do not show up -- the card shared with something
 //     that holds CUs for that long -- the workgroup raises the flag coop_err, which travels to the host with the outputs,
 //     and runs on to the end (the grid always drains); bk_wait then clears the counters and recomputes the request with
-//     the one-CU form.
+//     the one-CU form.  The failure is STICKY on the device until then: the workgroup also raises the engine's poison word
+//     (bk_internal.h), and cooperative launches already queued behind the failed one check it at entry, raise their own
+//     request's flag and do not wait for anybody -- their counters are not trustworthy and their outputs are redone too.
 template <int SC, int SR, int RH>
 struct CoopTiles {
     static_assert((SC == 1 || SC == 2 || SC == 4 || SC == 8) && (SR == 1 || SR == 3) && (6 / SR) % RH == 0 && SC * SR > 1,
@@ -643,7 +645,12 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
         Wr0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 0, 0));
         Wr1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 8192, 0));
     }
-    if (tid == 0) dead = 0;
+    if (tid == 0) {
+        // an earlier launch of this engine timed out and the host has not cleared the counters yet: do not trust them
+        const bool poisoned = __hip_atomic_load(a.coop_sync + BK_COOP_POISON_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (poisoned) atomicMax(a.coop_err, a.coop_tag);
+        dead = poisoned;
+    }
     STAMP(0);
     stage_input<1, THREADS>(a, actb, bg, 1, tid);
     __syncthreads();
@@ -693,6 +700,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > COOP_SPIN_LIMIT) {
                         atomicMax(a.coop_err, a.coop_tag);
+                        __hip_atomic_store(a.coop_sync + BK_COOP_POISON_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         dead = 1;
                         break;
                     }

@@ -95,6 +95,10 @@ struct Game {
     uint64_t n_value_evals = 0, n_policy_evals = 0, n_requests = 0;
     float final_score = 0.f;
     bool manual = false;  // driven from outside: rollouts are added, moves chosen/played by the caller
+    // MCTS.rollout(n, analyze_dict) (mcts.py:143-147): while on, every descent longer than two nodes is remembered
+    // under the root child it went through (path[1] -> path[1:]; a later descent through the same child replaces it)
+    bool analyze = false;
+    std::unordered_map<int, std::vector<int>> variations;
 
     Game(const bk_search_params& p, uint64_t seed) : prm(p), rng(seed) {}
 
@@ -102,6 +106,13 @@ struct Game {
     static bool same(const bk_pos& a, const bk_pos& b) {
         return a.ko == b.ko && a.last_move == b.last_move && ((a.turn ^ b.turn) & 1) == 0 &&
                std::memcmp(a.board, b.board, 81) == 0;
+    }
+    int find(const bk_pos& p) const {   // node id of a position, -1 if the tree has never seen it
+        auto it = table.find(key_hash(p));
+        if (it == table.end()) return -1;
+        for (int id : it->second)
+            if (same(poses[id], p)) return id;
+        return -1;
     }
     int intern(const bk_pos& p) {
         auto& bucket = table[key_hash(p)];
@@ -285,6 +296,7 @@ struct Game {
     bool has_request() const { return !req_policy.empty() || !req_value.empty(); }
 
     void reroot(int id) {  // MCTS.set_root (mcts.py:153-157): keep the subtree, expand the new root
+        variations.clear();
         root = id;
         if (prm.prune) prune();
         state = S_ROOT_EXPAND;
@@ -343,6 +355,7 @@ struct Game {
                             id = select(id);
                             path.push_back(id);
                         }
+                        if (analyze && path.size() > 2) variations[path[1]].assign(path.begin() + 1, path.end());
                         if (!nodes[path.back()].has_value &&
                             std::find(req_value.begin(), req_value.end(), path.back()) == req_value.end())
                             req_value.push_back(path.back());
@@ -374,6 +387,7 @@ struct Game {
                         }
                     }
                     moves.push_back((int16_t)nodes[best].mv);
+                    variations.clear();
                     root = best;
                     if (prm.prune) prune();
                     state = S_ROOT_EXPAND;
@@ -407,6 +421,7 @@ struct Game {
 
 struct bk_pool {
     std::vector<Game> games;
+    int row_cap = 0;              // the smallest `cap` a collect was called with: no single request may outgrow it
     std::vector<int> active;      // games included in the last collect, in batch order
     std::vector<int> pol_off, val_off;
     int threads = 1;
@@ -451,6 +466,12 @@ template <typename Emit>
 int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     const int G = (int)p->games.size();
     std::vector<char> wants(G, 0);
+    if (p->row_cap == 0 || cap < p->row_cap) {
+        // a request grows by speculative rows up to prm.speculate_rows: never beyond what one collect can take (a request
+        // that cannot fit would be skipped for ever: ADVICE r2).  A request without speculation is <= 82 rows <= cap.
+        p->row_cap = cap;
+        for (auto& gm : p->games) gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
+    }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
     for (int g = 0; g < G; ++g) {
         Game& gm = p->games[g];
@@ -569,6 +590,13 @@ void bk_pool_set_manual(bk_pool* p, int on) {
     for (auto& g : p->games) g.manual = on != 0;
 }
 
+void bk_pool_set_speculation(bk_pool* p, int speculate, int rows) {   // see bk_search_params.speculate / speculate_rows
+    for (auto& g : p->games) {
+        g.prm.speculate = speculate;
+        g.prm.speculate_rows = p->row_cap > 0 ? std::min(rows, p->row_cap) : rows;
+    }
+}
+
 int bk_pool_add_rollouts(bk_pool* p, int g, int n) {
     if (g < 0 || g >= (int)p->games.size() || n < 0) return -1;
     p->games[g].remaining += n;
@@ -612,6 +640,91 @@ int bk_pool_root_pos(const bk_pool* p, int g, bk_pos* out) {
     if (g < 0 || g >= (int)p->games.size() || p->games[g].root < 0) return -1;
     *out = p->games[g].poses[p->games[g].root];
     return 0;
+}
+
+/* ---- read-only views of the tree (the reference keeps N / V / children as dicts anybody may read, mcts.py:46-52) ---- */
+void bk_pool_set_analyze(bk_pool* p, int on) {
+    for (auto& g : p->games) {
+        g.analyze = on != 0;
+        g.variations.clear();
+    }
+}
+
+int bk_pool_variation(const bk_pool* p, int g, int move, int32_t* ids, int cap) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    if (gm.root < 0) return 0;
+    const TNode& r = gm.nodes[gm.root];
+    for (int i = 0; i < r.n_kids; ++i) {
+        const int c = gm.kid_ids[r.kids_off + i];
+        if (gm.nodes[c].mv != move) continue;
+        auto it = gm.variations.find(c);
+        if (it == gm.variations.end()) return 0;
+        const int n = std::min((int)it->second.size(), cap);
+        for (int k = 0; k < n; ++k) ids[k] = it->second[k];
+        return (int)it->second.size();
+    }
+    return 0;
+}
+
+int bk_pool_find(const bk_pool* p, int g, const bk_pos* pos) {
+    if (g < 0 || g >= (int)p->games.size() || !pos) return -1;
+    return p->games[g].find(*pos);
+}
+
+int bk_pool_root_id(const bk_pool* p, int g) { return (g < 0 || g >= (int)p->games.size()) ? -1 : p->games[g].root; }
+
+int bk_pool_node(const bk_pool* p, int g, int id, bk_node_info* out, bk_pos* pos) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    if (id < 0 || id >= (int)gm.nodes.size()) return -1;
+    const TNode& n = gm.nodes[id];
+    if (out) {
+        out->N = n.N;
+        out->n_children = n.n_kids;
+        out->V = n.V;
+        out->value = n.value;
+        out->move = (int16_t)n.mv;
+        out->flags = (uint16_t)((n.expanded ? BK_NODE_EXPANDED : 0) | (n.terminal ? BK_NODE_TERMINAL : 0) |
+                                (n.has_value ? BK_NODE_HAS_VALUE : 0) | (n.has_prior ? BK_NODE_HAS_PRIOR : 0));
+    }
+    if (pos) *pos = gm.poses[id];
+    return 0;
+}
+
+int bk_pool_node_children(const bk_pool* p, int g, int id, int32_t* ids, int cap) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    if (id < 0 || id >= (int)gm.nodes.size()) return -1;
+    const TNode& n = gm.nodes[id];
+    for (int i = 0; i < n.n_kids && i < cap; ++i) ids[i] = gm.kid_ids[n.kids_off + i];
+    return n.n_kids;
+}
+
+int bk_pool_node_prior(const bk_pool* p, int g, int id, double* prior) {
+    if (g < 0 || g >= (int)p->games.size() || !prior) return -1;
+    const Game& gm = p->games[g];
+    if (id < 0 || id >= (int)gm.nodes.size() || !gm.nodes[id].has_prior) return -1;
+    std::memcpy(prior, &gm.priors[gm.nodes[id].prior_off], 81 * sizeof(double));
+    return 0;
+}
+
+int bk_pool_principal_variation(const bk_pool* p, int g, int16_t* moves, int cap) {
+    if (g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    int id = gm.root, n = 0;
+    while (id >= 0 && gm.nodes[id].n_kids > 0 && n < cap) {   // most visited child at every level, lowest move on ties
+        const TNode& nd = gm.nodes[id];
+        int best = -1, best_n = 0;
+        for (int i = 0; i < nd.n_kids; ++i) {
+            const int c = gm.kid_ids[nd.kids_off + i];
+            if (gm.nodes[c].N > best_n) { best = c; best_n = gm.nodes[c].N; }
+        }
+        if (best < 0) break;
+        moves[n++] = (int16_t)gm.nodes[best].mv;
+        id = best;
+    }
+    return n;
 }
 
 int bk_pool_root_children(const bk_pool* p, int g, int16_t* moves, int32_t* N, double* V) {

@@ -256,8 +256,6 @@ class _GTPProtocol:
             return False, "usage: analyze <color> <interval>"
         if self._side(args[0]) != turn % 2:
             return False, f"it is not {args[0]}'s turn"
-        if not hasattr(self, "N"):
-            return False, "analyze needs the Python tree (start with --python-tree)"
         return self.analyze(int(args[1]))
 
     def _c_pondering(self, args, turn):
@@ -308,14 +306,20 @@ class _GTPProtocol:
         yield "= \n"
         while True:
             self.timed_rollout(interval / 200.0, analyze_dict=variations)
-            best = sorted(variations, key=lambda n: self.N[n])
-            out = ""
-            for n in best[-k:]:
-                pv = go.unsquash([m.last_move for m in variations[n]])
-                prior = self.root.dist.probs[n.last_move]
-                out += (f"info move {go.unsquash(n.last_move)} visits {self.N[n]} winrate {10000 * (1 - n.winrate):.0f} "
-                        f"prior {10000 * prior:.0f} pv " + " ".join(pv) + " ")
-            yield out + "\n"
+            yield self.analyze_line(variations, k)
+
+    def analyze_line(self, variations, k=3):
+        """One info line from the variations a search has collected: the k most visited root children, best last, each
+        with visits, winrate (from the mover's side, x 10,000), prior and the last line searched through it.  Ties in the
+        visit count are ordered by the move, so that the Python and the native tree print the same line."""
+        best = sorted(variations, key=lambda n: (self.N[n], -n.last_move))
+        probs = self.root.dist.probs
+        out = ""
+        for n in best[-k:]:
+            pv = go.unsquash([m.last_move for m in variations[n]])
+            out += (f"info move {go.unsquash(n.last_move)} visits {self.N[n]} winrate {10000 * (1 - n.winrate):.0f} "
+                    f"prior {10000 * probs[n.last_move]:.0f} pv " + " ".join(pv) + " ")
+        return out + "\n"
 
 
 class GTP(_GTPProtocol, MCTS):
@@ -355,7 +359,7 @@ def main(argv=None):
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     ap.add_argument("--ponder", action="store_true")
-    ap.add_argument("--python-tree", action="store_true", help="search with the Python tree (needed for `analyze`)")
+    ap.add_argument("--python-tree", action="store_true", help="search with the Python tree instead of the native one")
     args = ap.parse_args(argv)
 
     from . import nnet

@@ -6,11 +6,16 @@ core (csrc/bk_tree.cpp), for fast `genmove`.
 
 The search is the same algorithm as bokego_amd.mcts.MCTS (tests compare them visit for visit); only
 the tree lives in C++ and Python sees snapshots: `root` and the nodes returned by `choose()` are
-position objects (go.Game subclasses with `make_move`, `_terminal`, ...), and statistics are read
-with `child_stats()` / `N` of the root's children rather than through dicts keyed by every node.
+position objects (go.Game subclasses with `make_move`, `_terminal`, `dist`, `winrate`, ...).  The
+reference's observable dicts -- `tree.N[node]`, `tree.V[node]`, `tree.Q[node]`, `tree.children[node]`
+(mcts.py:46-52; GTP.analyze reads `self.N[n]`, gtp.py:386,395) -- are read-only mapping views that
+look a node up by its position in the native tree; `rollout(n, analyze_dict)` fills the caller's dict
+with the variations exactly as mcts.py:143-147 does, so `analyze` runs on the native search.
 """
 import ctypes
+from collections.abc import Mapping
 
+import numpy as np
 
 from . import go, nnet, selfplay
 
@@ -50,6 +55,65 @@ class Position(go.Game):
     def winrate(self):
         return None if self.tree is None else self.tree.winrate(self)
 
+    @property
+    def dist(self):
+        """The node's move distribution as the search uses it (Go_MCTS.dist, mcts.py:371-383): a Categorical over the 81
+        points once the policy has been evaluated for this node, else None."""
+        return None if self.tree is None else self.tree._dist(self)
+
+    @property
+    def value(self):
+        return None if self.tree is None else self.tree._value(self)
+
+
+class _TreeView(Mapping):
+    """Read-only dict-like view of one statistic of the native tree, keyed by position (any go.Game): what the
+    reference exposes as the defaultdicts MCTS.N / MCTS.V / MCTS.Q (a position the tree has never seen reads 0)."""
+
+    def __init__(self, tree, field):
+        self._tree, self._field = tree, field
+
+    def __getitem__(self, node):
+        info = self._tree._node_info(node)
+        return 0 if info is None or self._field is None else getattr(info, self._field)
+
+    def get(self, node, default=0):
+        info = self._tree._node_info(node)
+        return default if info is None else (0 if self._field is None else getattr(info, self._field))
+
+    def __contains__(self, node):
+        return self._tree._find(node) >= 0
+
+    def __len__(self):
+        return self._tree._pool.info(0)["n_nodes"]
+
+    def __iter__(self):
+        return (self._tree._position(i) for i in range(len(self)))
+
+
+class _ChildrenView(Mapping):
+    """MCTS.children: node -> set of child nodes, for expanded nodes (mcts.py:52,185-192)."""
+
+    def __init__(self, tree):
+        self._tree = tree
+
+    def __getitem__(self, node):
+        i = self._tree._find(node)
+        if i < 0 or not self._tree._node_at(i).flags & 1:
+            raise KeyError(node)
+        return {self._tree._position(c) for c in self._tree._children_ids(i)}
+
+    def __contains__(self, node):
+        i = self._tree._find(node)
+        return i >= 0 and bool(self._tree._node_at(i).flags & 1)
+
+    def __len__(self):
+        return sum(1 for _ in self)
+
+    def __iter__(self):
+        n = self._tree._pool.info(0)["n_nodes"]
+        return (self._tree._position(i) for i in range(n) if self._tree._node_at(i).flags & 1)
+
 
 class NativeMCTS:
     """kwargs as the reference's MCTS: expand_thresh, exploration_weight, noise_weight, device; plus
@@ -82,13 +146,16 @@ class NativeMCTS:
         # one-CU workgroups (1.85 -> 1.45 ms/move at 1600 rollouts over the first 40 moves); the fp32 kernel's small-batch
         # launch gives a board 4 CUs up to 64 rows, 3 up to 80 but only 2 from 81, so there a request takes speculative rows
         # only while it stays within 80 (1.91 -> 1.79 ms/move over 80-move games; with 128 or 256 rows it gets SLOWER).
-        prec = getattr(getattr(ev, "engine", None), "precision", None)
-        spec_default = (50, 256) if prec == "f16x2" else (50, 80) if prec == "f32" else (0, 128)
+        # Both follow the engine's precision when it is switched later (engine.set_precision), unless given explicitly.
+        self._spec_kw = (kwargs.get("speculate"), kwargs.get("speculate_rows"))
+        self._spec_prec = self._engine_precision()
+        spec = self._spec_defaults(self._spec_prec)
         prm = selfplay.search_params(rollouts=0, expand_thresh=self.expand_thresh, c_puct=self.exploration_weight,
                                      noise_weight=self.noise_weight, max_turns=MAX_TURNS, prune=kwargs.get("prune", 0),
-                                     speculate=kwargs.get("speculate", spec_default[0]),
-                                     speculate_rows=kwargs.get("speculate_rows", spec_default[1]))
+                                     speculate=spec[0], speculate_rows=spec[1])
         self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=kwargs.get("cap", 1024), threads=1)
+        self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, None)   # Q: simulations are off
+        self.children = _ChildrenView(self)
         self._lib = self._pool._lib
         self._lib.bk_pool_set_manual(self._pool._h, 1)
         self.komi = getattr(root, "komi", 5.5) if root is not None else 5.5
@@ -97,8 +164,19 @@ class NativeMCTS:
         self._pump()
 
     # ---- plumbing ------------------------------------------------------------------------------------
+    def _engine_precision(self):
+        return getattr(getattr(self.evaluator, "engine", None), "precision", None)
+
+    def _spec_defaults(self, prec):
+        d = (50, 256) if prec == "f16x2" else (50, 80) if prec == "f32" else (0, 128)
+        return tuple(d[i] if self._spec_kw[i] is None else self._spec_kw[i] for i in (0, 1))
+
     def _pump(self):
         """Run the native search until it needs nothing more (every outstanding rollout done)."""
+        prec = self._engine_precision()
+        if prec != self._spec_prec:           # engine.set_precision() since the last call: the other kernel's defaults
+            self._spec_prec = prec
+            self._lib.bk_pool_set_speculation(self._pool._h, *self._spec_defaults(prec))
         while True:
             if getattr(self.evaluator, "wants_positions", False):
                 feats, npol = self._pool.collect_positions()   # planes are encoded on the GPU
@@ -107,6 +185,46 @@ class NativeMCTS:
             if len(feats) == 0:
                 return
             self._pool.deliver(*self.evaluator(feats, npol))
+
+    # node ids <-> positions (ids are valid until the next re-rooting of a pruning tree: never cached here)
+    def _find(self, node):
+        return self._lib.bk_pool_find(self._pool._h, 0, ctypes.byref(node._pos))
+
+    def _node_at(self, i):
+        info = selfplay.NodeInfo()
+        if self._lib.bk_pool_node(self._pool._h, 0, int(i), ctypes.byref(info), None):
+            raise IndexError(i)
+        return info
+
+    def _node_info(self, node):
+        i = self._find(node)
+        return None if i < 0 else self._node_at(i)
+
+    def _position(self, i):
+        pos = go.Pos()
+        if self._lib.bk_pool_node(self._pool._h, 0, int(i), None, ctypes.byref(pos)):
+            raise IndexError(i)
+        return Position._from_pos(pos, self.komi, self)
+
+    def _children_ids(self, i):
+        ids = np.empty(81, np.int32)
+        n = self._lib.bk_pool_node_children(self._pool._h, 0, int(i), ids.ctypes.data, 81)
+        return ids[:max(n, 0)].tolist()
+
+    def _dist(self, node):
+        i = self._find(node)
+        pr = np.empty(81, np.float64)
+        if i < 0 or self._lib.bk_pool_node_prior(self._pool._h, 0, i, pr.ctypes.data):
+            return None
+        import torch
+        t = torch.from_numpy(pr.astype(np.float32))
+        d = torch.distributions.Categorical(probs=t, validate_args=False)
+        d.probs = t       # exactly what the search uses (the constructor renormalises once more; the reference overwrites
+        return d          # dist.probs the same way, mcts.py:357,369,381)
+
+    def _value(self, node):
+        info = self._node_info(node)
+        return None if info is None or not info.flags & 4 else float(info.value)
 
     def _set_position(self, node):
         if self._lib.bk_pool_set_position(self._pool._h, 0, ctypes.byref(node._pos)):
@@ -121,8 +239,27 @@ class NativeMCTS:
         return r
 
     def rollout(self, n=1, analyze_dict=None):
+        """n rollouts from the root (mcts.py:133-151).  analyze_dict: as in the reference, every descent longer than two
+        nodes is stored under the root child it went through (child -> [child, ..., leaf]); the native search records the
+        node ids, the dict receives position objects."""
+        if analyze_dict is not None:
+            self._lib.bk_pool_set_analyze(self._pool._h, 1)
         self._lib.bk_pool_add_rollouts(self._pool._h, 0, int(n))
         self._pump()
+        if analyze_dict is not None:
+            ids = np.empty(128, np.int32)
+            for mv in self.child_stats():
+                k = self._lib.bk_pool_variation(self._pool._h, 0, int(mv), ids.ctypes.data, 128)
+                if k > 0:
+                    line = [self._position(i) for i in ids[:min(k, 128)]]
+                    analyze_dict[line[0]] = line
+            self._lib.bk_pool_set_analyze(self._pool._h, 0)
+
+    def principal_variation(self):
+        """Moves of the most visited line from the root."""
+        mv = np.empty(128, np.int16)
+        n = self._lib.bk_pool_principal_variation(self._pool._h, 0, mv.ctypes.data, 128)
+        return mv[:max(n, 0)].tolist()
 
     def choose(self, node=None):
         """Most visited child of the root becomes the new root (mcts.py:110-131)."""
@@ -158,15 +295,15 @@ class NativeMCTS:
         self._pump()
 
     def winrate(self, node=None):
-        """(V/N + 1)/2 of the root (or of one of its children)."""
-        if node is None or node.key() == self.root.key():
+        """(V/N + 1)/2 of the root, or of any node of the tree (mcts.py:159-170); 0 for an unvisited one."""
+        if node is None:
             gi = self._pool.info(0)
             n, v = gi["root_N"], gi["root_V"]
         else:
-            st = self.child_stats().get(node.last_move)
-            if st is None or self.root.make_move(node.last_move).key() != node.key():
+            info = self._node_info(node)
+            if info is None:
                 return 0
-            n, v = st
+            n, v = info.N, info.V
         return (v / n + 1) / 2 if n > 0 else 0
 
     def child_stats(self):

@@ -33,6 +33,11 @@ class SearchParams(ctypes.Structure):
                 ("speculate_rows", ctypes.c_int32)]
 
 
+class NodeInfo(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("n_children", ctypes.c_int32), ("V", ctypes.c_double), ("value", ctypes.c_float),
+                ("move", ctypes.c_int16), ("flags", ctypes.c_uint16)]
+
+
 class GameInfo(ctypes.Structure):
     _fields_ = [("done", ctypes.c_int32), ("n_moves", ctypes.c_int32), ("score", ctypes.c_float),
                 ("n_nodes", ctypes.c_int32), ("n_value_evals", ctypes.c_uint64), ("n_policy_evals", ctypes.c_uint64),
@@ -60,6 +65,15 @@ TREE_SYMBOLS = {
     "bk_pool_play": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int]),
     "bk_pool_set_position": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
     "bk_pool_root_pos": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
+    "bk_pool_set_speculation": (None, [_VP, ctypes.c_int, ctypes.c_int]),
+    "bk_pool_find": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
+    "bk_pool_root_id": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "bk_pool_node": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NodeInfo), _VP]),
+    "bk_pool_node_children": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int]),
+    "bk_pool_node_prior": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP]),
+    "bk_pool_principal_variation": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int]),
+    "bk_pool_set_analyze": (None, [_VP, ctypes.c_int]),
+    "bk_pool_variation": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int]),
 }
 _tree_ready = False
 

@@ -49,7 +49,11 @@ typedef struct bk_search_params {
                               the tree is not touched: the search is the same search, rollout for rollout; only
                               n_value_evals / n_requests differ.  0: off                                     */
     int32_t speculate_rows; /* a request takes speculative rows only while it stays within this many rows
-                              (default 128: the range of the engine's cooperative small-batch launch)          */
+                              (default 128: the range of the engine's cooperative small-batch launch); clamped to
+                              the `cap` of bk_pool_collect*, so that no request can outgrow a collect.  The
+                              "same search" statement holds for networks whose outputs do not depend on the batch a
+                              row travels in: the fp32 kernel always, the f16x2 kernel except for a request redone in
+                              fp32 after an fp16-range overflow (the rows sharing that request change with it)     */
 } bk_search_params;
 
 typedef struct bk_game_info {
@@ -97,6 +101,8 @@ int bk_pool_game_visits(const bk_pool *p, int g, int ply, int16_t *moves, int32_
  *   bk_pool_set_position  = set_root(Go_MCTS(board=...))  (clear_board, handicap)
  */
 void bk_pool_set_manual(bk_pool *p, int on);
+/* change bk_search_params.speculate / speculate_rows of every game (e.g. after the engine's precision was switched) */
+void bk_pool_set_speculation(bk_pool *p, int speculate, int rows);
 int bk_pool_add_rollouts(bk_pool *p, int g, int n);
 int bk_pool_choose(bk_pool *p, int g);
 int bk_pool_play(bk_pool *p, int g, int move);
@@ -104,6 +110,41 @@ int bk_pool_set_position(bk_pool *p, int g, const bk_pos *pos);
 int bk_pool_root_pos(const bk_pool *p, int g, bk_pos *out);
 /* root children of game g in ascending move order; returns their number */
 int bk_pool_root_children(const bk_pool *p, int g, int16_t *moves, int32_t *N, double *V);
+
+/*
+ * Read-only views of a game's tree.  The reference keeps Q / N / V / children as dicts keyed by node that anybody may
+ * read (mcts.py:46-52; GTP.analyze reads self.N[n], gtp.py:386,395); here a node is an id, found by its position:
+ *   bk_pool_find            id of the node with this (board, ko, last move, side), -1 if the tree never saw it
+ *   bk_pool_node            statistics (+ the 192-byte position) of node `id`
+ *   bk_pool_node_children   ids of its children (as linked by expansion); returns their number
+ *   bk_pool_node_prior      its 81 move priors (the Categorical-normalised policy, noise included); -1 if not evaluated
+ *   bk_pool_principal_variation   the moves of the most visited line from the root
+ * Ids stay valid until the next re-rooting of a pruning tree (prm.prune).
+ * bk_pool_set_analyze(on) + bk_pool_variation: MCTS.rollout(n, analyze_dict) (mcts.py:143-147) -- while on, every
+ * descent longer than two nodes is remembered under the root child it passed through; bk_pool_variation copies the node
+ * ids of the remembered line (the child first) for the root child reached by `move` and returns its length (0: none).
+ * Switching analysis on or off, and every re-rooting, forgets the remembered lines.
+ */
+#define BK_NODE_EXPANDED 1
+#define BK_NODE_TERMINAL 2
+#define BK_NODE_HAS_VALUE 4
+#define BK_NODE_HAS_PRIOR 8
+typedef struct bk_node_info {
+    int32_t N;          /* visits (MCTS.N[node])                                   */
+    int32_t n_children;
+    double V;           /* summed backed-up values (MCTS.V[node])                  */
+    float value;        /* the ValueNet's output for this position (Go_MCTS.value) */
+    int16_t move;       /* the move that leads here (last_move)                    */
+    uint16_t flags;     /* BK_NODE_*                                               */
+} bk_node_info;
+int bk_pool_find(const bk_pool *p, int g, const bk_pos *pos);
+int bk_pool_root_id(const bk_pool *p, int g);
+int bk_pool_node(const bk_pool *p, int g, int id, bk_node_info *out, bk_pos *pos);
+int bk_pool_node_children(const bk_pool *p, int g, int id, int32_t *ids, int cap);
+int bk_pool_node_prior(const bk_pool *p, int g, int id, double *prior);
+int bk_pool_principal_variation(const bk_pool *p, int g, int16_t *moves, int cap);
+void bk_pool_set_analyze(bk_pool *p, int on);
+int bk_pool_variation(const bk_pool *p, int g, int move, int32_t *ids, int cap);
 
 #ifdef __cplusplus
 }

@@ -151,3 +151,29 @@ def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
             assert tree.choose().last_move == ref["move"]
     a, p = ahead._pool.info(0), plain._pool.info(0)
     assert a["n_requests"] < 0.8 * p["n_requests"] and a["n_value_evals"] > p["n_value_evals"]
+
+
+def test_analyze_and_tree_views_on_the_native_tree_on_gpu(sds):
+    """VERDICT r2 item 4 on the HIP engine: the default launcher's tree (NativeGTP) serves `analyze` from the search it
+    is running (gtp.py:374-399) -- the same info line as the Python tree prints after the same rollouts -- and lets
+    callers read N / V / children of any node (gtp.py:386,395 read self.N[n])."""
+    from bokego_amd import nnet
+    from bokego_amd.gtp import GTP, NativeGTP
+    from bokego_amd.mcts import Go_MCTS
+    from bokego_amd.mcts_native import Position
+    mk = lambda cls, root: cls(root, nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1]), no_sim=True, time_lim=None, n_rollouts=200)  # noqa: E731
+    py, nat = mk(GTP, Go_MCTS()), mk(NativeGTP, Position())
+    out = []
+    for g in (py, nat):
+        g.running = True
+        assert g.send("play b e5") == "= \n\n"
+        var = {}
+        g.rollout(1600, analyze_dict=var)
+        out.append((g.analyze_line(var, k=3), {n.last_move: [m.last_move for m in line] for n, line in var.items()}))
+    assert out[0] == out[1] and out[1][0].count("info move") == 3
+    for node, n in py.N.items():
+        assert nat.N[node] == n and abs(nat.V[node] - py.V[node]) < 1e-9
+    assert {k.key() for k in nat.children[nat.root]} == {k.key() for k in py.children[py.root]}
+    assert torch.equal(nat.root.dist.probs, py.root.dist.probs)
+    gen = nat.send("analyze w 10")
+    assert next(gen) == "= \n" and next(gen).startswith("info move ")

@@ -528,3 +528,33 @@ def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
     for k in ref:
         assert np.array_equal(ref[k], bad[k]) and np.array_equal(ref[k], good[k]), k
     eng.close()
+
+
+def test_cooperative_failure_is_sticky_for_requests_queued_behind_it(monkeypatch):
+    """A is submitted with a deserting slice, B and C right behind it, all three cooperative, before
+    anything is waited for.  A's peers time out and raise the engine's poison word; B and C run before the host has
+    cleared the counters, see the word at entry, flag themselves and are redone by bk_wait as well: nobody hands out
+    results computed on stale counters.  D, submitted after the waits, is an ordinary clean cooperative launch."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    xs = [make_batch(n, seed_base=6_000 + 100 * i, dtype=np.uint8) for i, n in enumerate((48, 30, 62, 17))]
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=64)
+    monkeypatch.setenv("BK_COOP", "0")
+    refs = [eng.eval(x, logits=True, probs=True, value=True, n_policy=3) for x in xs]
+    monkeypatch.delenv("BK_COOP")
+    monkeypatch.setenv("BK_COOP_FAULT", "1")
+    tA = eng.submit(xs[0], logits=True, probs=True, value=True, n_policy=3)
+    monkeypatch.delenv("BK_COOP_FAULT")
+    tB = eng.submit(xs[1], logits=True, probs=True, value=True, n_policy=3)
+    tC = eng.submit(xs[2], logits=True, probs=True, value=True, n_policy=3)
+    outs = [eng.wait(tA), eng.wait(tB), eng.wait(tC)]
+    st = eng.stats()
+    assert st["coop_launches"] == 3 and st["coop_fallbacks"] == 3
+    outs.append(eng.eval(xs[3], logits=True, probs=True, value=True, n_policy=3))
+    st = eng.stats()
+    assert st["coop_launches"] == 4 and st["coop_fallbacks"] == 3
+    for ref, out in zip(refs, outs):
+        for k in ref:
+            assert np.array_equal(ref[k], out[k]), k
+    eng.close()

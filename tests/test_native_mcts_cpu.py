@@ -77,3 +77,79 @@ def test_speculative_evaluation_does_not_change_the_search(prune):
     info = {s: t._pool.info(0) for s, t in trees.items()}
     assert info[8]["n_requests"] < info[0]["n_requests"] and info[15]["n_requests"] < info[0]["n_requests"]
     assert info[8]["n_value_evals"] >= info[0]["n_value_evals"]
+
+
+def test_native_tree_is_observable_like_the_reference_dicts():
+    """`tree.N[node]`, `tree.V[node]`, `tree.children[node]` read-only views on the native tree
+    (the reference exposes them as dicts, mcts.py:46-52) agree with the Python tree's dicts for every node it holds."""
+    f = FakeNets()
+    py = MCTS(Go_MCTS(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=6)
+    nat = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=6)
+    for _ in range(3):
+        py.rollout(200); nat.rollout(200)
+        for node, n in py.N.items():
+            assert nat.N[node] == n and nat.V[node] == py.V[node], node
+            assert abs(nat.winrate(node) - py.winrate(node)) < 1e-12
+        for node in py.children:
+            kids = py.children[node]
+            assert node in nat.children and {k.key() for k in nat.children[node]} == {k.key() for k in kids}
+        assert nat.Q[nat.root] == 0 and nat.N[Position(turn=1)] == 0 and Position(turn=1) not in nat.N
+        with pytest.raises(KeyError):
+            nat.children[Position(turn=1)]
+        r = nat.root
+        assert torch.equal(r.dist.probs, py.root.dist.probs) and r.value == py.root._value
+        leaf = next(k for k in nat.children[r] if nat.N[k] == 0) if any(nat.N[k] == 0 for k in nat.children[r]) else None
+        assert leaf is None or leaf.dist is None
+        # the most visited line: follows the most visited child at every level
+        pv, node = nat.principal_variation(), py.root
+        for mv in pv:
+            node = max(sorted(py.children[node], key=lambda c: c.mv), key=lambda c: py.N[c])
+            assert node.mv == mv
+        py.choose(); nat.choose()
+    with pytest.raises(TypeError):
+        nat.N[nat.root] = 3
+
+
+def test_analyze_on_the_native_tree_prints_the_python_trees_lines():
+    """`analyze` (gtp.py:374-399) served by the search that is running, on both trees: after the same rollouts from the
+    transcript's position the collected variations and the info line are the same, text for text."""
+    from oracle.oracle import OraclePolicy, OracleValue
+    P = _Wrap(OraclePolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw"))))
+    V = _Wrap(OracleValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))), True)
+    kw = dict(no_sim=True, time_lim=None, n_rollouts=100, expand_thresh=20)
+    a, b = GTP(Go_MCTS(), P, V, **kw), NativeGTP(Position(), P, V, **kw)
+    lines = []
+    for g in (a, b):
+        g.running = True
+        assert g.send("play b e5") == "= \n\n"
+        var = {}
+        g.rollout(150, analyze_dict=var)
+        g.rollout(150, analyze_dict=var)           # the caller's dict accumulates over calls, later lines replace earlier ones
+        lines.append((g.analyze_line(var, k=3), {n.last_move: [m.last_move for m in line] for n, line in var.items()}))
+    assert lines[0] == lines[1]
+    text = lines[1][0]
+    assert text.count("info move") == 3 and " visits " in text and " winrate " in text and " prior " in text and " pv " in text
+    # through the protocol: the generator answers "= ", then info lines
+    gen = b.send("analyze w 10")
+    assert next(gen) == "= \n" and next(gen).startswith("info move ")
+    assert b.send("analyze b 10") == "? it is not b's turn\n\n"
+
+
+def test_speculation_defaults_follow_the_engines_precision():
+    """the speculation defaults come from the engine's precision and are re-derived when it is switched."""
+    class Eng:
+        precision = "f16x2"
+    class Ev:
+        engine = Eng()
+        def __call__(self, feats, n_policy):
+            return np.full((n_policy, 81), 1 / 81, np.float32), np.zeros(len(feats), np.float32)
+    ev = Ev()
+    t = NativeMCTS(Position(), evaluator=ev, cap=128)
+    assert t._spec_defaults("f16x2") == (50, 256) and t._spec_defaults("f32") == (50, 80)
+    t.rollout(300)              # cap=128 < 256 speculative rows: the request is clamped to a collect's capacity, nothing is dropped
+    assert t._pool.info(0)["root_N"] == 300
+    ev.engine.precision = "f32"
+    t.rollout(10)
+    assert t._spec_prec == "f32"
+    keep = NativeMCTS(Position(), evaluator=ev, speculate=7, speculate_rows=99)
+    assert keep._spec_defaults("f16x2") == (7, 99)
