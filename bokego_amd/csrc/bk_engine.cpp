@@ -67,8 +67,11 @@ struct bk_engine {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
     size_t ev_head = 0, ev_pending = 0;
-    // device-pointer path, f16x2: [0] = sequence number of the last call whose f16x2 kernel overflowed (what gates that
-    // call's fp32 redo kernel), [1] = number of calls redone
+    // device-pointer path, f16x2: a ring of BK_DEV_FLAGS words, one per call (call number % BK_DEV_FLAGS), zeroed in stream
+    // order in front of the call's f16x2 kernel, which raises it to the call number on overflow: that is what gates the
+    // call's fp32 redo kernel.  One word per call, so calls running concurrently on different caller streams cannot hide
+    // each other's overflow (with ONE shared word, atomicMax(flag, N) was a no-op once call N+1 had raised it: ADVICE r2).
+    // [BK_DEV_FLAGS] = number of calls redone.
     unsigned int* d_dev_flag = nullptr;
     unsigned int dev_seq = 0;
     // cooperative small-batch launches (ticket path on the compute stream only: one exchange buffer): the exchange buffer
@@ -340,6 +343,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         r.overflow = nullptr;
         r.gate = d_flag;
         r.gate_tag = tag;
+        r.gate_counter = e->d_dev_flag + BK_DEV_FLAGS;
         return bk_launch_leaf_eval(r, nb, stream);
     };
     // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
@@ -480,9 +484,9 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
     e->dev_allocs.push_back(e->d_stamps);
 #endif
-    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, 2 * sizeof(unsigned int)));
+    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, (BK_DEV_FLAGS + 1) * sizeof(unsigned int)));
     e->dev_allocs.push_back(e->d_dev_flag);
-    TRY_CREATE(hipMemset(e->d_dev_flag, 0, 2 * sizeof(unsigned int)));
+    TRY_CREATE(hipMemset(e->d_dev_flag, 0, (BK_DEV_FLAGS + 1) * sizeof(unsigned int)));
     {
         const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
@@ -704,9 +708,11 @@ int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, in
     HIP_TRY(e, hipSetDevice(e->device));
     // `stream` is used as given: NULL is HIP's null (legacy default) stream, which is also what
     // torch.cuda.current_stream() is unless the caller switched streams.
-    if (++e->dev_seq == 0) e->dev_seq = 1;  // 2^32 calls later a stale tag could match: skip 0, the flag's reset value
+    if (++e->dev_seq == 0) e->dev_seq = 1;  // 0 is the flag's reset value
+    unsigned int* flag = e->d_dev_flag + e->dev_seq % BK_DEV_FLAGS;   // this call's own word (see d_dev_flag)
+    if (e->precision == BK_PRECISION_F16X2 && B > 0) HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(unsigned int), static_cast<hipStream_t>(stream)));
     return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
-                   static_cast<hipStream_t>(stream), e->precision, e->d_dev_flag, e->dev_seq, true);
+                   static_cast<hipStream_t>(stream), e->precision, flag, e->dev_seq, true);
 }
 
 int bk_engine_set_precision(bk_engine* e, int precision) {
@@ -740,11 +746,11 @@ int bk_stats(bk_engine* e, bk_stats_t* out) {
         drain_events(e);
     }
     if (e->d_dev_flag && e->dev_seq) {  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
-        unsigned int f[2] = {0, 0};
+        unsigned int f = 0;
         HIP_TRY(e, hipSetDevice(e->device));
         HIP_TRY(e, hipDeviceSynchronize());  // the calls may sit on any caller stream
-        HIP_TRY(e, hipMemcpy(f, e->d_dev_flag, sizeof(f), hipMemcpyDeviceToHost));
-        e->st.f16_device_overflow = f[1];
+        HIP_TRY(e, hipMemcpy(&f, e->d_dev_flag + BK_DEV_FLAGS, sizeof(f), hipMemcpyDeviceToHost));
+        e->st.f16_device_overflow = f;
     }
     *out = e->st;
     return BK_OK;

@@ -55,8 +55,9 @@ struct bk_eval_args {
     unsigned int* overflow;      // f16x2: raised to overflow_tag (atomicMax) if an activation left the fp16 range
     unsigned int overflow_tag;   //   (result unreliable); host-buffer path: 1, device-pointer path: the call's sequence number
     // exact-fp32 kernel launched as the REDO of an f16x2 call on the device-pointer path: every workgroup returns at
-    // once unless gate[0] == gate_tag (the f16x2 kernel of the same call raised the flag); gate[1] counts redone calls
+    // once unless gate[0] == gate_tag (the f16x2 kernel of the same call raised the call's flag word)
     unsigned int* gate;
+    unsigned int* gate_counter;  // counts redone calls
     unsigned int gate_tag;
     int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
     // cooperative (cout-split) launches for small batches, bk_kernels.hip: exchange buffer [BK_COOP_MAX_TASKS][2][81][128]
@@ -74,6 +75,8 @@ struct bk_eval_args {
 // slot = 16g + 4kq + j is what MFMA k-step j of channel group g consumes from lane quad kq; chosen so that the k order
 // of every dot product equals the round-1 kernel's (bit-identical results)
 static inline int bk_slot_perm(int s) { return (s & ~15) | (((s >> 1) & 1) << 3) | (((s >> 2) & 1) << 2) | ((s & 1) << 1) | ((s >> 3) & 1); }
+
+#define BK_DEV_FLAGS 256   // device-pointer path: overflow flag words, one per call in flight (bk_engine.cpp, d_dev_flag)
 
 #define BK_POS_BYTES 192  // sizeof(bk_pos), include/bokego_go.h
 

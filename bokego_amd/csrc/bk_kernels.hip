@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
-        if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate + 1, 1u);
+        if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate_counter, 1u);
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;

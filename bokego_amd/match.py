@@ -8,6 +8,7 @@ A referee board (bokego_amd.go) validates every move and scores the final positi
     python -m bokego_amd.match --games 20 -r 400 --opponent policy
     python -m bokego_amd.match --games 100 -r 1600 --opponent "gnugo --mode gtp --chinese-rules"
     python -m bokego_amd.match --games 100 -r 1600 --opening-plies 4 --opponent "python -m oracle.gtp_cpu -r 1600"   # CPU-backend baseline
+    tools/run_cfg4.sh            # BASELINE configs[4] as written (needs a `gnugo` binary): both backends against GNU Go
 """
 import argparse
 import json
@@ -233,21 +234,37 @@ def main(argv=None):
     ap.add_argument("--opening-plies", type=int, default=0, help="seeded random opening moves per game pair (variety between deterministic engines)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None)
+    ap.add_argument("--engine", default=None, help="GTP command line of side A instead of the in-process HIP engine "
+                                                   "(e.g. the CPU-backend engine: \"python -m oracle.gtp_cpu -r 1600\")")
+    ap.add_argument("--engine-name", default=None)
+    ap.add_argument("--opponent-name", default=None)
+    ap.add_argument("--json-out", default=None, help="also write the result (without the move records) to this file")
     args = ap.parse_args(argv)
-    from . import nnet
-    from .gtp import NativeGTP, load_state_dict
-    from .mcts_native import Position
-    pi = nnet.HipPolicyNet(load_state_dict(args.p), precision=args.precision)
-    val = nnet.HipValueNet(load_state_dict(args.v), precision=args.precision)
-    a = InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=args.r),
-                        name=f"boke-hip-r{args.r}")
+    pi = None
+    if args.engine is None or args.opponent == "policy":
+        from . import nnet
+        from .gtp import NativeGTP, load_state_dict
+        from .mcts_native import Position
+        pi = nnet.HipPolicyNet(load_state_dict(args.p), precision=args.precision)
+    if args.engine is None:
+        val = nnet.HipValueNet(load_state_dict(args.v), precision=args.precision)
+        a = InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=args.r),
+                            name=args.engine_name or f"boke-hip-r{args.r}")
+    else:
+        a = SubprocessEngine(args.engine, name=args.engine_name)
     if args.opponent == "policy":
         b = PolicyEngine(pi)
     else:
-        b = SubprocessEngine(args.opponent)
+        b = SubprocessEngine(args.opponent, name=args.opponent_name)
     res = play_match(a, b, args.games, args.komi, args.sgf, args.opening_plies, args.seed, progress=sys.stderr)
     res.pop("records")
+    res.update(engine=args.engine or f"in-process HIP engine, -r {args.r}, precision {args.precision or 'f32'}",
+               opponent=args.opponent, komi=args.komi, opening_plies=args.opening_plies, seed=args.seed)
     print(json.dumps(res))
+    if args.json_out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
+        with open(args.json_out, "w") as f:
+            json.dump(res, f, indent=1)
     a.close()
     b.close()
 

@@ -530,6 +530,34 @@ def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
     eng.close()
 
 
+def test_f16x2_overflow_flags_are_per_call_across_caller_streams(weights, gold):
+    """two overflowing bk_eval_device calls on two caller streams, enqueued back to back so that they can run
+    concurrently (the later call's kernel may raise its flag first).  Every call owns a flag word, so both are redone in
+    fp32; with one shared word the earlier call's atomicMax was a no-op and its clamped outputs were kept."""
+    import torch
+    from bokego_amd.engine import LeafEngine
+    rng = np.random.default_rng(11)
+    bigs = [(rng.integers(0, 8, size=(n, 27, 9, 9)) * 4000.0).astype(np.float32) for n in (1500, 90, 700, 333)]
+    fast = LeafEngine(weights[0], weights[1], max_batch=2048, precision="f16x2")
+    exact = LeafEngine(weights[0], weights[1], max_batch=2048, precision="f32")
+    streams = [torch.cuda.Stream() for _ in bigs]
+    xs = [torch.from_numpy(b).cuda() for b in bigs]
+    torch.cuda.synchronize()
+    outs = []
+    for x, st in zip(xs, streams):                      # no synchronisation between the calls
+        with torch.cuda.stream(st):
+            outs.append(fast.eval_device(x, logits=True, probs=True, value=True))
+    torch.cuda.synchronize()
+    for x, o in zip(xs, outs):
+        ref = exact.eval_device(x, logits=True, probs=True, value=True)
+        torch.cuda.synchronize()
+        for k in ("logits", "probs", "value"):
+            assert torch.equal(o[k], ref[k]), k
+    assert fast.stats()["f16_device_overflow"] == len(bigs)
+    fast.close()
+    exact.close()
+
+
 def test_cooperative_failure_is_sticky_for_requests_queued_behind_it(monkeypatch):
     """A is submitted with a deserting slice, B and C right behind it, all three cooperative, before
     anything is waited for.  A's peers time out and raise the engine's poison word; B and C run before the host has

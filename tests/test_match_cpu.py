@@ -77,3 +77,31 @@ def test_random_openings_and_cpu_backend_engine_as_subprocess():
     op = match.random_opening(4, 3)
     assert all(rec["moves"][:4] == op for rec in res["records"])
     assert res["ms_per_move"]["boke-cpu"] > 0
+
+
+def test_match_cli_with_two_subprocess_engines_and_json_out(tmp_path, capsys):
+    """`python -m bokego_amd.match --engine ... --opponent ... --json-out ...` (what tools/run_cfg4.sh drives for the
+    CPU-backend leg): both sides behind pipes, no HIP engine is constructed, the summary is printed and written."""
+    import json
+    script = tmp_path / "passer.py"
+    script.write_text(
+        "import sys\n"
+        "for line in sys.stdin:\n"
+        "    c = line.split()\n"
+        "    if not c: continue\n"
+        "    out = 'pass' if c[0] == 'genmove' else ''\n"
+        "    sys.stdout.write('= ' + out + '\\n\\n'); sys.stdout.flush()\n"
+        "    if c[0] == 'quit': break\n")
+    out = tmp_path / "res" / "m.json"
+    match.main(["--games", "2", "--engine", f"{sys.executable} {script}", "--engine-name", "a", "--opponent",
+                f"{sys.executable} {script}", "--opponent-name", "b", "--json-out", str(out)])
+    printed = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    saved = json.load(open(out))
+    assert printed == saved and saved["games"] == 2 and saved["a_wins"] + saved["b_wins"] == 2 and "records" not in saved
+    assert saved["opponent"].endswith("passer.py") and saved["komi"] == 5.5
+    # tools/run_cfg4.sh refuses to start without a gnugo binary (exit 3) instead of failing half-way
+    import shutil
+    import subprocess
+    if shutil.which("gnugo") is None:
+        r = subprocess.run([os.path.join(REPO, "tools", "run_cfg4.sh")], capture_output=True, text=True, env={**os.environ, "GNUGO": ""})
+        assert r.returncode == 3 and "no gnugo" in r.stdout
