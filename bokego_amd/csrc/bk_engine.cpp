@@ -4,15 +4,19 @@
 //   boke.py:30-38 (construct + load_state_dict + eval), mcts.py:74-76 (.to(device)),
 //   nnet.py:265-297 (policy_dist / value / policy_sample forward calls).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bokego_amd.h"
@@ -22,8 +26,123 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// roctx ranges around the requests, so that a rocprofv3 --marker-trace timeline shows "bk_submit B=.. np=.." / "bk_wait"
+// above the kernels and copies they enqueue ("roctx ranges around bk_eval").  The marker library is looked up at
+// run time (no link dependency; an engine on a box without it simply has no ranges) when BK_ROCTX is set -- tools that
+// profile set it; an unprofiled run does not pay for the calls.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (!getenv("BK_ROCTX")) return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RoctxRange {   // RAII: every return path of the C-ABI functions closes its range
+    bool on;
+    explicit RoctxRange(const char* what, int B = -1, int np = -1) : on(roctx().push != nullptr) {
+        if (!on) return;
+        char buf[96];
+        if (B >= 0) snprintf(buf, sizeof buf, "%s B=%d n_policy=%d", what, B, np);
+        else snprintf(buf, sizeof buf, "%s", what);
+        roctx().push(buf);
+    }
+    ~RoctxRange() {
+        if (on) roctx().pop();
+    }
+};
+
 #define BK_STAMP_BLOCKS 16384
 constexpr double kBnEps = 1e-5;  // torch.nn.BatchNorm default, nnet.py:33,98-99
+
+// Staging of a large host buffer (the reference-shaped call: f32 planes, 35.8 MB at B = 4,096): a single memcpy into the
+// pinned slot runs at ~10 GB/s and the H2D copy only starts behind it -- 3.5 + 0.7 ms in front of an 8 ms kernel.  Here a
+// few worker threads copy the buffer slice by slice while the submitting thread enqueues each slice's H2D copy as soon as
+// that slice has landed, so staging costs about as long as the slower of the two (both ~0.7 ms).  BK_COPY_THREADS=0 turns it
+// off.  Workers sleep on a condition variable between requests.
+class CopyPool {
+public:
+    static constexpr int kMaxSlices = 64;
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // copy src -> dst in `n` slices of `slice` bytes (the last one shorter); ready(i) is called on the calling thread, in
+    // order, once slice i is in place
+    template <typename Ready>
+    bool copy(void* dst, const void* src, size_t bytes, size_t slice, Ready ready) {
+        const int n = (int)((bytes + slice - 1) / slice);
+        if (n > kMaxSlices) return false;
+        for (int i = 0; i < n; ++i) done_[i].store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = static_cast<char*>(dst);
+            src_ = static_cast<const char*>(src);
+            bytes_ = bytes;
+            slice_ = slice;
+            n_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            ++gen_;
+        }
+        cv_.notify_all();
+        bool ok = true;
+        for (int i = 0; i < n; ++i) {
+            while (!done_[i].load(std::memory_order_acquire)) std::this_thread::yield();
+            ok = ready(i) && ok;
+        }
+        return ok;
+    }
+
+private:
+    void run() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || gen_ != seen; });
+                if (quit_) return;
+                seen = gen_;
+            }
+            for (;;) {
+                const int i = next_.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n_) break;
+                const size_t off = (size_t)i * slice_;
+                std::memcpy(dst_ + off, src_ + off, std::min(slice_, bytes_ - off));
+                done_[i].store(1, std::memory_order_release);
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool quit_ = false;
+    unsigned long gen_ = 0;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0, slice_ = 0;
+    int n_ = 0;
+    std::atomic<int> next_{0};
+    std::atomic<int> done_[kMaxSlices];
+};
 
 struct Slot {  // one in-flight host-buffer request
     int64_t ticket = 0;
@@ -57,6 +176,7 @@ struct bk_engine {
     // one request overlap the kernel of another (MI355X has separate SDMA engines per direction)
     hipStream_t stream = nullptr;       // compute
     hipStream_t s_in = nullptr, s_out = nullptr;
+    CopyPool* copy_pool = nullptr;      // created by the first large host-buffer request
     std::vector<void*> dev_allocs;
     bk_net_params net[2]{};
     Slot slots[BK_MAX_INFLIGHT];
@@ -520,6 +640,7 @@ int bk_engine_destroy(bk_engine* e) {
     for (void* d : e->dev_allocs) (void)hipFree(d);
     for (hipStream_t st : {e->s_in, e->stream, e->s_out})
         if (st) (void)hipStreamDestroy(st);
+    delete e->copy_pool;
     delete e;
     return BK_OK;
 }
@@ -531,6 +652,7 @@ constexpr int kSrcPositions = 2;  // beside BK_FEATS_F32 (0) / BK_FEATS_U8 (1)
 // common body of the ticket entry points; src_kind: BK_FEATS_F32, BK_FEATS_U8 or kSrcPositions
 int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_policy, int want, float* logits,
                       float* probs, float* values) {
+    RoctxRange range(src_kind == kSrcPositions ? "bk_submit_positions" : "bk_submit", B, n_policy);
     int rc = check_want(e, B, n_policy, want);
     if (rc) return rc;
     if (B > 0 && !src) return fail(e, BK_ERR_ARG, src_kind == kSrcPositions ? "positions is NULL" : "feats is NULL");
@@ -548,8 +670,28 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     const bool chained = B > 256;
     hipStream_t sin = chained ? e->s_in : e->stream, sout = chained ? e->s_out : e->stream;
     if (B > 0) {
-        std::memcpy(s->h_in, src, bytes);
-        HIP_TRY(e, hipMemcpyAsync(src_kind == kSrcPositions ? s->d_pos : s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, sin));
+        void* d_dst = src_kind == kSrcPositions ? s->d_pos : s->d_in;
+        static const int copy_threads = [] { const char* v = getenv("BK_COPY_THREADS"); return v ? atoi(v) : 6; }();
+        bool staged = false;
+        if (bytes >= ((size_t)4 << 20) && copy_threads > 0) {   // slices of >= 1 MiB, copied by the pool, H2D per slice
+            if (!e->copy_pool) e->copy_pool = new (std::nothrow) CopyPool(std::min(copy_threads, 16));
+            if (e->copy_pool) {
+                const size_t slice = std::max<size_t>((size_t)1 << 20, (bytes / 24 + 4095) & ~(size_t)4095);
+                hipError_t herr = hipSuccess;
+                staged = e->copy_pool->copy(s->h_in, src, bytes, slice, [&](int i) {
+                    const size_t off = (size_t)i * slice;
+                    const hipError_t rc = hipMemcpyAsync(static_cast<char*>(d_dst) + off, static_cast<char*>(s->h_in) + off,
+                                                         std::min(slice, bytes - off), hipMemcpyHostToDevice, sin);
+                    if (rc != hipSuccess) herr = rc;
+                    return rc == hipSuccess;
+                });
+                HIP_TRY(e, herr);
+            }
+        }
+        if (!staged) {
+            std::memcpy(s->h_in, src, bytes);
+            HIP_TRY(e, hipMemcpyAsync(d_dst, s->h_in, bytes, hipMemcpyHostToDevice, sin));
+        }
         // The encoder (13 us per 4,096 records) runs on the COMPUTE stream, in front of the request's leaf kernel.  Round 1
         // launched it on the copy-in stream so that it overlapped the previous request's leaf kernel; under that
         // kernel its workgroups wait for CUs, so it "ran" 110-370 us per call (6-8 % of the summed kernel time of a
@@ -640,6 +782,7 @@ int bk_encode_positions(bk_engine* e, const void* positions, int B, uint8_t* pla
 
 int bk_wait(bk_engine* e, int64_t ticket) {
     if (!e) return BK_ERR_ARG;
+    RoctxRange range("bk_wait");
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
         HIP_TRY(e, hipEventSynchronize(s.done));
@@ -698,6 +841,7 @@ int bk_eval_device(bk_engine* e, const void* d_feats, int feats_dtype, int B, in
 
 int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, int B, int n_policy, int want,
                           float* d_logits, float* d_probs, float* d_values, void* stream) {
+    RoctxRange range("bk_eval_device", B, n_policy);
     int rc = check_want(e, B, n_policy, want);
     if (rc) return rc;
     if (feats_dtype != BK_FEATS_F32 && feats_dtype != BK_FEATS_U8) return fail(e, BK_ERR_ARG, "bad feats_dtype");

@@ -214,16 +214,28 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     const int lane16 = lane * 16;
     int boff = PRELOADED ? 2 * 8192 : 0;                // scalar: byte offset of the group being fetched
     auto load_w = [&](f32x4 (&W)[CTW]) {
+#if BK_EXP & 2   // timing experiment (make exp EXP=2|3): no weight traffic in the loops -- results are wrong
+        (void)W;
+#else
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
             W[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16 + ct * 1024, boff, 0));
+#endif
         boff += 8192;
     };
     auto read_a = [&](f32x4 (&A)[RT], int imm) {
+#if BK_EXP & 1   // timing experiment (make exp EXP=1|3): no LDS reads in the loops -- results are wrong
+        (void)A; (void)imm;
+#else
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
+#endif
     };
     f32x4 A0[RT], A1[RT];                               // activations: ping-pong per group (weights: ring, 2 groups ahead)
+#if BK_EXP & 1
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { A0[rt] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)lane; A1[rt] = f32x4{.5f, .25f, .125f, 1.f} * (float)lane; }
+#endif
 
     // One group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
     // taps: the interior tiles always run, every edge tile sits behind a wave-uniform branch (specialised copies of the

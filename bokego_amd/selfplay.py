@@ -338,9 +338,13 @@ def shard_game_ids(n_games, rank, world):
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
-              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None):
-    """Play this rank's share of a generation; returns (local result dict, reduced stats dict)."""
-    gids = shard_game_ids(n_games, rank, world)
+              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None):
+    """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
+    gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
+    `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
+    a later job) with the same games coming out; the reference's launcher can only raise when a worker fails
+    (bin/selfplay.py:196-199).  The statistics returned are those of the games played here."""
+    gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits)
     if n_pools is None:
@@ -470,6 +474,8 @@ def main():
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
+    ap.add_argument("--replay-shard", metavar="RANK/WORLD", default=None,
+                    help="re-play the games a failed rank owned (e.g. 3/8: the gids with gid %% 8 == 3) in this process")
     args = ap.parse_args()
 
     import torch
@@ -494,9 +500,13 @@ def main():
     eng = LeafEngine(load(args.policy, "policy_19.bkw"), load(args.value, "value_synth.bkw"), device_id=local_rank,
                      max_batch=args.max_batch, precision=args.precision)
     ev = EngineEvaluator(eng, gpu_encode=not args.host_encode)
+    gids = None
+    if args.replay_shard:
+        r, w = (int(v) for v in args.replay_shard.split("/"))
+        gids = shard_game_ids(args.games, r, w)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
-                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)))
+                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)), gids=gids)
     secs = local["seconds"]
     if world > 1:
         t = torch.tensor([secs], dtype=torch.float64, device="cuda")

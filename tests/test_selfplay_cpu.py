@@ -230,3 +230,23 @@ def test_collect_positions_equals_collect_features():
         b.deliver(probs, vals)
         steps += 1
     assert steps > 20 and [a.moves(g) for g in range(4)] == [b.moves(g) for g in range(4)]
+
+
+def test_a_dead_ranks_shard_can_be_replayed_anywhere():
+    """SURVEY 5 (failure handling): games are pure functions of (seed_base + gid, networks), so the shard of a rank that
+    died is re-played by passing its game ids -- same moves, same scores, same statistics as the rank would have reported;
+    survivors' totals + the replayed shard's = the whole generation's."""
+    f = FakeNets()
+    mk = lambda: selfplay.CallableEvaluator(f.policy, f.value)  # noqa: E731
+    whole, _ = selfplay.self_play(mk(), rank=0, world=1, **KW)
+    world = 3
+    ranks = [selfplay.self_play(mk(), rank=r, world=world, **KW)[0] for r in range(world)]
+    dead = 1
+    replay, named = selfplay.self_play(mk(), rank=0, world=1, gids=selfplay.shard_game_ids(KW["n_games"], dead, world), **KW)
+    assert replay["games"] == ranks[dead]["games"] and np.array_equal(replay["local_stats"], ranks[dead]["local_stats"])
+    assert named["games"] == len(ranks[dead]["games"])
+    total = sum(ranks[r]["local_stats"] for r in range(world) if r != dead) + replay["local_stats"]
+    assert np.array_equal(total, whole["local_stats"])
+    assert {**ranks[0]["games"], **replay["games"], **ranks[2]["games"]} == whole["games"]
+    empty, named = selfplay.self_play(mk(), gids=[], **KW)
+    assert empty["games"] == {} and named["games"] == 0

@@ -18,7 +18,7 @@ precision = sys.argv[2] if len(sys.argv) > 2 else None
 pi, val = nnet.HipPolicyNet(precision=precision), nnet.HipValueNet(precision=precision)
 pi.load_state_dict(load_bkw(os.path.join(G, "policy_19.bkw")))
 val.load_state_dict(load_bkw(os.path.join(G, "value_synth.bkw")))
-kw = {}          # BK_SPECULATE / BK_SPECULATE_ROWS override NativeMCTS's defaults (on for f16x2 engines, off for fp32)
+kw = {}          # BK_SPECULATE / BK_SPECULATE_ROWS override NativeMCTS's defaults (N = 50 with 256 rows on f16x2 engines, 80 rows on fp32 ones)
 if "BK_SPECULATE" in os.environ:
     kw["speculate"] = int(os.environ["BK_SPECULATE"])
 if "BK_SPECULATE_ROWS" in os.environ:
