@@ -159,6 +159,7 @@ struct Slot {  // one in-flight host-buffer request
     void* d_pos = nullptr;  // position records (bk_submit_positions): encoded into d_in on the GPU
     int dtype = 0;
     hipEvent_t in_ready = nullptr;   // H2D of this request finished (copy-in stream)
+    hipEvent_t head_ready = nullptr; // ... of its first part (large requests are launched in two parts)
     hipEvent_t computed = nullptr;   // kernel of this request finished (compute stream)
     hipEvent_t done = nullptr;       // D2H of this request finished (copy-out stream)
     bool busy = false;
@@ -342,6 +343,7 @@ int alloc_slot(bk_engine* e, Slot& s) {
     HIP_TRY(e, hipMemset(s.d_out, 0, 64));
     std::memset(s.h_out, 0, 64);
     HIP_TRY(e, hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&s.head_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     return BK_OK;
@@ -354,6 +356,7 @@ void free_slot(Slot& s) {
     if (s.d_pos) (void)hipFree(s.d_pos);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.in_ready) (void)hipEventDestroy(s.in_ready);
+    if (s.head_ready) (void)hipEventDestroy(s.head_ready);
     if (s.computed) (void)hipEventDestroy(s.computed);
     if (s.done) (void)hipEventDestroy(s.done);
     s = Slot{};
@@ -422,21 +425,30 @@ LaunchPlan plan_launch(int B_policy, int B_value, int n_cu, int precision) {
 // d_flag/tag: where and with what value the f16x2 kernel reports an activation outside the fp16 range.
 // gated_redo (device-pointer path, f16x2): the exact-fp32 kernel follows on the same stream with the same launch plan,
 // gated on d_flag[0] == tag -- stream-ordered, no host round trip, and a few microseconds when nothing overflowed.
+// lo / hi: evaluate only positions [lo, hi) of the request (hi < 0: all B) -- a large host-buffer request is launched in two
+// parts so that the first runs while the rest of its planes is still on the way (submit_common); buffers and row indices are
+// those of the whole request.
 int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, int want, float* d_logits,
             float* d_probs, float* d_values, hipStream_t stream, int precision, unsigned int* d_flag,
-            unsigned int tag = 1, bool gated_redo = false, bool allow_coop = false) {
+            unsigned int tag = 1, bool gated_redo = false, bool allow_coop = false, int lo = 0, int hi = -1) {
     if (B == 0) return BK_OK;
+    if (hi < 0) hi = B;
+    const bool whole = lo == 0 && hi == B;
     bk_eval_args a{};
     a.net[0] = e->net[0];
     a.net[1] = e->net[1];
     a.feats = d_feats;
     a.feats_dtype = dtype;
-    a.B_policy = (want & (BK_WANT_LOGITS | BK_WANT_PROBS)) ? n_policy : 0;
-    a.B_value = (want & BK_WANT_VALUE) ? B : 0;
+    const int np_all = (want & (BK_WANT_LOGITS | BK_WANT_PROBS)) ? n_policy : 0;
+    a.off_p = std::min(lo, np_all);
+    a.B_policy = std::min(hi, np_all);
+    a.off_v = (want & BK_WANT_VALUE) ? lo : 0;
+    a.B_value = (want & BK_WANT_VALUE) ? hi : 0;
     a.logits = (want & BK_WANT_LOGITS) ? d_logits : nullptr;
     a.probs = (want & BK_WANT_PROBS) ? d_probs : nullptr;
     a.values = (want & BK_WANT_VALUE) ? d_values : nullptr;
-    if (a.B_policy + a.B_value == 0) return BK_OK;
+    const int cnt_p = a.B_policy - a.off_p, cnt_v = a.B_value - a.off_v;   // rows of each net in this launch
+    if (cnt_p + cnt_v == 0) return BK_OK;
 #ifdef BK_STAMPS
     a.stamps = e->d_stamps;
 #endif
@@ -469,7 +481,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
     // "cooperative form").  A workgroup that gives up waiting for its peers raises word 1 of the slot's flag block, which
     // travels to the host with the outputs: bk_wait then redoes the request with the one-CU form.
-    if (const int slices = (allow_coop && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag &&
+    if (const int slices = (allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag &&
                             !getenv("BK_FORCE_NB")) ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0) {
         a.coop_xchg = e->d_coop_xchg;
         a.coop_sync = e->d_coop_sync;
@@ -488,17 +500,17 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
         return BK_OK;
     }
-    const LaunchPlan pl = plan_launch(a.B_policy, a.B_value, e->n_cu, precision);
+    const LaunchPlan pl = plan_launch(cnt_p, cnt_v, e->n_cu, precision);
     const int nb1 = pl.nb1, head_p = pl.head_p, head_v = pl.head_v, tail_nb = pl.tail_nb;
     if (tail_nb) {
         bk_eval_args h = a;
-        h.B_policy = 3 * head_p;
-        h.B_value = 3 * head_v;
+        h.B_policy = a.off_p + 3 * head_p;
+        h.B_value = a.off_v + 3 * head_v;
         h.gate_count = 0;  // the tail launch counts for the call
         HIP_TRY(e, launch(h, 3));
         bk_eval_args t = a;
-        t.off_p = 3 * head_p;
-        t.off_v = 3 * head_v;
+        t.off_p = a.off_p + 3 * head_p;
+        t.off_v = a.off_v + 3 * head_v;
         HIP_TRY(e, launch(t, tail_nb));
         e->st.split_launches += 1;
     } else {
@@ -509,8 +521,8 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
         ++e->ev_pending;
     }
-    e->st.evals += (uint64_t)B;
-    e->st.batches += 1;
+    e->st.evals += (uint64_t)(hi - lo);
+    e->st.batches += lo == 0 ? 1 : 0;
     if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
     return BK_OK;
 }
@@ -671,26 +683,45 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     hipStream_t sin = chained ? e->s_in : e->stream, sout = chained ? e->s_out : e->stream;
     if (B > 0) {
         void* d_dst = src_kind == kSrcPositions ? s->d_pos : s->d_in;
-        static const int copy_threads = [] { const char* v = getenv("BK_COPY_THREADS"); return v ? atoi(v) : 6; }();
-        bool staged = false;
-        if (bytes >= ((size_t)4 << 20) && copy_threads > 0) {   // slices of >= 1 MiB, copied by the pool, H2D per slice
-            if (!e->copy_pool) e->copy_pool = new (std::nothrow) CopyPool(std::min(copy_threads, 16));
-            if (e->copy_pool) {
-                const size_t slice = std::max<size_t>((size_t)1 << 20, (bytes / 24 + 4095) & ~(size_t)4095);
-                hipError_t herr = hipSuccess;
-                staged = e->copy_pool->copy(s->h_in, src, bytes, slice, [&](int i) {
-                    const size_t off = (size_t)i * slice;
-                    const hipError_t rc = hipMemcpyAsync(static_cast<char*>(d_dst) + off, static_cast<char*>(s->h_in) + off,
-                                                         std::min(slice, bytes - off), hipMemcpyHostToDevice, sin);
-                    if (rc != hipSuccess) herr = rc;
-                    return rc == hipSuccess;
-                });
-                HIP_TRY(e, herr);
+        const char* ct_env = bytes >= ((size_t)4 << 20) ? getenv("BK_COPY_THREADS") : nullptr;
+        const int copy_threads = ct_env ? atoi(ct_env) : 6;
+        // bytes [b0, b1) of the request: host buffer -> pinned slot -> device, on the copy-in stream
+        auto stage = [&](size_t b0, size_t b1) -> int {
+            const size_t n = b1 - b0;
+            char* hsrc = static_cast<char*>(s->h_in) + b0;
+            char* ddst = static_cast<char*>(d_dst) + b0;
+            if (n >= ((size_t)4 << 20) && copy_threads > 0) {   // slices of >= 1 MiB, copied by the pool, H2D per slice
+                if (!e->copy_pool) e->copy_pool = new (std::nothrow) CopyPool(std::min(copy_threads, 16));
+                if (e->copy_pool) {
+                    const size_t slice = std::max<size_t>((size_t)1 << 20, (n / 24 + 4095) & ~(size_t)4095);
+                    hipError_t herr = hipSuccess;
+                    const bool ok = e->copy_pool->copy(hsrc, static_cast<const char*>(src) + b0, n, slice, [&](int i) {
+                        const size_t off = (size_t)i * slice;
+                        const hipError_t rc = hipMemcpyAsync(ddst + off, hsrc + off, std::min(slice, n - off), hipMemcpyHostToDevice, sin);
+                        if (rc != hipSuccess) herr = rc;
+                        return rc == hipSuccess;
+                    });
+                    HIP_TRY(e, herr);
+                    if (ok) return BK_OK;
+                }
             }
-        }
-        if (!staged) {
-            std::memcpy(s->h_in, src, bytes);
-            HIP_TRY(e, hipMemcpyAsync(d_dst, s->h_in, bytes, hipMemcpyHostToDevice, sin));
+            std::memcpy(hsrc, static_cast<const char*>(src) + b0, n);
+            HIP_TRY(e, hipMemcpyAsync(ddst, hsrc, n, hipMemcpyHostToDevice, sin));
+            return BK_OK;
+        };
+        // A large request of feature planes is evaluated in two parts: the first kHeadRows positions (two full rounds of
+        // 3-board workgroups when both nets run) are launched as soon as THEIR planes have arrived and run while the rest is
+        // still being staged and copied -- the reference-shaped call (f32 planes from host memory, 35.8 MB at B = 4,096)
+        // then costs the kernel plus ~0.2 ms instead of plus 1.3 ms.  Results do not depend on how a request is launched.
+        constexpr int kHeadRows = 768;
+        const size_t row_bytes = bytes / (size_t)B;
+        const bool two_part = chained && src_kind != kSrcPositions && B >= 3 * kHeadRows && bytes >= ((size_t)16 << 20) && !getenv("BK_NO_HEAD_PART");
+        if (two_part) {
+            if ((rc = stage(0, (size_t)kHeadRows * row_bytes))) return rc;
+            HIP_TRY(e, hipEventRecord(s->head_ready, e->s_in));
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, s->head_ready, 0));
+        } else if ((rc = stage(0, bytes))) {
+            return rc;
         }
         // The encoder (13 us per 4,096 records) runs on the COMPUTE stream, in front of the request's leaf kernel.  Round 1
         // launched it on the copy-in stream so that it overlapped the previous request's leaf kernel; under that
@@ -701,7 +732,7 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
             HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             e->st.positions_encoded += (uint64_t)B;
         }
-        if (chained) {
+        if (chained && !two_part) {
             HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
             HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
         }
@@ -719,9 +750,22 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
             HIP_TRY(e, hipMemsetAsync(d_flag, 0, 2 * sizeof(unsigned int), e->stream));
             s->flag_dirty = false;
         }
-        rc = enqueue(e, s->d_in, dtype, B, n_policy, want, reinterpret_cast<float*>(s->d_out + s->off_logits),
-                     reinterpret_cast<float*>(s->d_out + s->off_probs), reinterpret_cast<float*>(s->d_out + s->off_values),
-                     e->stream, e->precision, d_flag, 1, false, /*allow_coop=*/true);
+        float* o_logits = reinterpret_cast<float*>(s->d_out + s->off_logits);
+        float* o_probs = reinterpret_cast<float*>(s->d_out + s->off_probs);
+        float* o_values = reinterpret_cast<float*>(s->d_out + s->off_values);
+        if (two_part) {
+            rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
+                         false, 0, kHeadRows);
+            if (rc) return rc;
+            if ((rc = stage((size_t)kHeadRows * row_bytes, bytes))) return rc;       // ... while the first part runs
+            HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, s->in_ready, 0));
+            rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
+                         false, kHeadRows, B);
+        } else {
+            rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
+                         /*allow_coop=*/true);
+        }
         if (rc) return rc;
         if (chained) {
             HIP_TRY(e, hipEventRecord(s->computed, e->stream));

@@ -586,3 +586,38 @@ def test_cooperative_failure_is_sticky_for_requests_queued_behind_it(monkeypatch
         for k in ref:
             assert np.array_equal(ref[k], out[k]), k
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, monkeypatch, precision):
+    """A large request of host planes is staged by a pool of copy threads and launched in two parts (the first 768
+    positions run while the rest is still on its way: bk_engine.cpp submit_common).  Outputs are bit-identical to the
+    single-launch path (BK_NO_HEAD_PART, BK_COPY_THREADS=0) for f32 and u8 planes, whole batches and policy prefixes on
+    either side of the split, pipelined tickets included."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x8 = make_batch(4096, seed_base=77_000, dtype=np.uint8)
+    eng = LeafEngine(weights[0], weights[1], max_batch=4096, precision=precision)
+    cases = [(4096, 4096, np.float32), (4096, 100, np.float32), (2305, 1000, np.float32), (2304, 768, np.float32), (4000, 0, np.float32)]
+    cases.append((4096, 4096, np.uint8))        # 9 MB: below the two-part threshold, the pool still stages it
+    def run(B, npol, dt):
+        x = x8[:B].astype(dt)
+        return eng.eval(x, logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
+    monkeypatch.setenv("BK_NO_HEAD_PART", "1")
+    monkeypatch.setenv("BK_COPY_THREADS", "0")
+    ref = {c: run(*c) for c in cases}
+    monkeypatch.delenv("BK_NO_HEAD_PART")
+    monkeypatch.delenv("BK_COPY_THREADS")
+    for c in cases:
+        got = run(*c)
+        for k in ref[c]:
+            assert np.array_equal(ref[c][k], got[k]), (c, k)
+    # three tickets in flight, each launched in two parts
+    xf = x8.astype(np.float32)
+    ts = [eng.submit(xf, logits=True, probs=True, value=True) for _ in range(3)]
+    for t in ts:
+        got = eng.wait(t)
+        for k in ref[cases[0]]:
+            assert np.array_equal(ref[cases[0]][k], got[k]), k
+    assert eng.stats()["evals"] >= 3 * 4096
+    eng.close()
