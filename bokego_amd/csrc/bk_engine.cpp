@@ -157,6 +157,11 @@ struct Slot {  // one in-flight host-buffer request
     bool flag_dirty = false;  // the device flag was raised: reset it before the slot's next f16x2 launch
     void* d_in = nullptr;
     void* d_pos = nullptr;  // position records (bk_submit_positions): encoded into d_in on the GPU
+    // the pinned blocks as the GPU addresses them: small fp32 requests skip both copies -- the encoder reads the position
+    // records straight from h_in and the leaf kernel writes flag + outputs straight into h_out (submit_common, "direct")
+    void* h_in_dev = nullptr;
+    char* h_out_dev = nullptr;
+    bool direct = false;    // this request's outputs were written to h_out by the kernel (no D2H copy was enqueued)
     int dtype = 0;
     hipEvent_t in_ready = nullptr;   // H2D of this request finished (copy-in stream)
     hipEvent_t head_ready = nullptr; // ... of its first part (large requests are launched in two parts)
@@ -342,6 +347,12 @@ int alloc_slot(bk_engine* e, Slot& s) {
     HIP_TRY(e, hipMalloc((void**)&s.d_out, out_max));
     HIP_TRY(e, hipMemset(s.d_out, 0, 64));
     std::memset(s.h_out, 0, 64);
+    // device-side addresses of the two pinned blocks (mapped into the device's address space by hipHostMalloc); a
+    // failure here only disables the direct path
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, s.h_in, 0) == hipSuccess) s.h_in_dev = dp;
+    if (hipHostGetDevicePointer(&dp, s.h_out, 0) == hipSuccess) s.h_out_dev = static_cast<char*>(dp);
+    (void)hipGetLastError();
     HIP_TRY(e, hipEventCreateWithFlags(&s.in_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.head_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
@@ -681,6 +692,14 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
     // stream and the two cross-stream event hops are saved; large ones use the three-stream chain
     const bool chained = B > 256;
     hipStream_t sin = chained ? e->s_in : e->stream, sout = chained ? e->s_out : e->stream;
+    // Small fp32 requests (the one-tree genmove regime: a 62-board expansion batch is a 108 us kernel) go "direct": no H2D
+    // copy of position records -- the encoder reads them from the pinned slot over PCIe (12 KB) -- and no D2H copy -- the
+    // leaf kernel writes the flag word and the outputs (a few hundred bytes) into the pinned output block, which the host
+    // reads after the request's event.  Two of the five enqueues and ~12 us of copy kernels per round trip disappear
+    // (rocprofv3 timeline, profiles/r03_genmove_timeline.md).  fp32 only: the f16x2 kernel's overflow flag is raised with
+    // an atomic max, which is not used on host memory here.  BK_NO_DIRECT=1 restores the copies.
+    const bool direct = !chained && B > 0 && e->precision == BK_PRECISION_F32 && s->h_in_dev && s->h_out_dev && !getenv("BK_NO_DIRECT");
+    s->direct = direct;
     if (B > 0) {
         void* d_dst = src_kind == kSrcPositions ? s->d_pos : s->d_in;
         const char* ct_env = bytes >= ((size_t)4 << 20) ? getenv("BK_COPY_THREADS") : nullptr;
@@ -716,7 +735,9 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         constexpr int kHeadRows = 768;
         const size_t row_bytes = bytes / (size_t)B;
         const bool two_part = chained && src_kind != kSrcPositions && B >= 3 * kHeadRows && bytes >= ((size_t)16 << 20) && !getenv("BK_NO_HEAD_PART");
-        if (two_part) {
+        if (direct && src_kind == kSrcPositions) {
+            std::memcpy(s->h_in, src, bytes);          // the encoder reads the records from here
+        } else if (two_part) {
             if ((rc = stage(0, (size_t)kHeadRows * row_bytes))) return rc;
             HIP_TRY(e, hipEventRecord(s->head_ready, e->s_in));
             HIP_TRY(e, hipStreamWaitEvent(e->stream, s->head_ready, 0));
@@ -729,7 +750,7 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  BK_ENCODE_OVERLAP=1 restores that.
         static const bool enc_overlap = getenv("BK_ENCODE_OVERLAP") != nullptr;
         if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
-            HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
+            HIP_TRY(e, bk_launch_encode(direct ? s->h_in_dev : s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             e->st.positions_encoded += (uint64_t)B;
         }
         if (chained && !two_part) {
@@ -745,14 +766,17 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         s->off_probs = s->off_values + (((want & BK_WANT_VALUE) ? (size_t)B * 4 : 0) + 63) / 64 * 64;
         s->off_logits = s->off_probs + (((want & BK_WANT_PROBS) ? (size_t)n_policy * 81 * 4 : 0) + 63) / 64 * 64;
         s->out_bytes = s->off_logits + ((want & BK_WANT_LOGITS) ? (size_t)n_policy * 81 * 4 : 0);
-        unsigned int* d_flag = reinterpret_cast<unsigned int*>(s->d_out);
-        if (s->flag_dirty) {  // only after a flag was seen raised: both words are zero otherwise
+        char* out_base = direct ? s->h_out_dev : s->d_out;
+        unsigned int* d_flag = reinterpret_cast<unsigned int*>(out_base);
+        if (direct) {
+            std::memset(s->h_out, 0, 2 * sizeof(unsigned int));   // host write before the launch: visible to the kernel
+        } else if (s->flag_dirty) {  // only after a flag was seen raised: both words are zero otherwise
             HIP_TRY(e, hipMemsetAsync(d_flag, 0, 2 * sizeof(unsigned int), e->stream));
             s->flag_dirty = false;
         }
-        float* o_logits = reinterpret_cast<float*>(s->d_out + s->off_logits);
-        float* o_probs = reinterpret_cast<float*>(s->d_out + s->off_probs);
-        float* o_values = reinterpret_cast<float*>(s->d_out + s->off_values);
+        float* o_logits = reinterpret_cast<float*>(out_base + s->off_logits);
+        float* o_probs = reinterpret_cast<float*>(out_base + s->off_probs);
+        float* o_values = reinterpret_cast<float*>(out_base + s->off_values);
         if (two_part) {
             rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
                          false, 0, kHeadRows);
@@ -771,7 +795,7 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
             HIP_TRY(e, hipEventRecord(s->computed, e->stream));
             HIP_TRY(e, hipStreamWaitEvent(e->s_out, s->computed, 0));
         }
-        HIP_TRY(e, hipMemcpyAsync(s->h_out, s->d_out, s->out_bytes, hipMemcpyDeviceToHost, sout));  // flag + all outputs
+        if (!direct) HIP_TRY(e, hipMemcpyAsync(s->h_out, s->d_out, s->out_bytes, hipMemcpyDeviceToHost, sout));  // flag + all outputs
     }
     HIP_TRY(e, hipEventRecord(s->done, sout));
     s->busy = true;

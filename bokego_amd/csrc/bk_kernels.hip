@@ -660,7 +660,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
     if (tid == 0) {
         // an earlier launch of this engine timed out and the host has not cleared the counters yet: do not trust them
         const bool poisoned = __hip_atomic_load(a.coop_sync + BK_COOP_POISON_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (poisoned) atomicMax(a.coop_err, a.coop_tag);
+        if (poisoned) __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         dead = poisoned;
     }
     STAMP(0);
@@ -711,7 +711,9 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > COOP_SPIN_LIMIT) {
-                        atomicMax(a.coop_err, a.coop_tag);
+                        // a plain system-scope store (every writer stores the same tag): the flag word may live in pinned
+                        // host memory, next to the outputs the kernel writes there directly for small requests
+                        __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(a.coop_sync + BK_COOP_POISON_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         dead = 1;
                         break;

@@ -621,3 +621,35 @@ def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, m
             assert np.array_equal(ref[cases[0]][k], got[k]), k
     assert eng.stats()["evals"] >= 3 * 4096
     eng.close()
+
+
+def test_small_requests_without_copies_give_the_same_bits(weights, monkeypatch):
+    """Small fp32 requests skip both copies ("direct": the encoder reads position records from the pinned slot, the leaf
+    kernel writes flag + outputs into the pinned output block).  Same bits as with the copies (BK_NO_DIRECT), for position
+    records and for planes, cooperative and one-CU forms, back-to-back tickets; the f16x2 engine keeps its copies."""
+    from bokego_amd import go
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x8, recs = make_batch(256, seed_base=91_000, dtype=np.uint8, with_records=True)
+    eng = LeafEngine(weights[0], weights[1], max_batch=512)
+    shapes = [(1, 1), (9, 1), (62, 1), (63, 63), (70, 3), (130, 0), (256, 256)]
+    def run(kind, B, npol):
+        kw = dict(logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
+        return eng.wait(eng.submit_positions(recs[:B], **kw)) if kind == "pos" else eng.eval(x8[:B], **kw)
+    monkeypatch.setenv("BK_NO_DIRECT", "1")
+    ref = {(k, *sh): run(k, *sh) for k in ("pos", "planes") for sh in shapes}
+    monkeypatch.delenv("BK_NO_DIRECT")
+    for key, want in ref.items():
+        got = run(*key)
+        for k in want:
+            assert np.array_equal(want[k], got[k]), (key, k)
+    # four tickets in flight on four slots, then their results in order
+    ts = [eng.submit_positions(recs[:B], logits=False, probs=True, value=True, n_policy=1) for B in (62, 17, 80, 5)]
+    for t, B in zip(ts, (62, 17, 80, 5)):
+        got = eng.wait(t)
+        want = ref[("pos", 62, 1)] if B == 62 else None
+        if want is not None:
+            assert np.array_equal(got["value"], want["value"]) and np.array_equal(got["probs"], want["probs"])
+        assert got["value"].shape == (B,) and np.isfinite(got["value"]).all()
+    assert eng.stats()["coop_fallbacks"] == 0
+    eng.close()

@@ -36,6 +36,26 @@ for prec, pat in (("f32", "bk_leaf_eval_kernel<"), ("f16x2", "bk_leaf_eval_f16_k
         w.writerows(r for r in rows if pat in r["Name"] or (prec == "f32" and "bk_leaf_eval_coop_kernel<" in r["Name"]))
 
 
+# per-dispatch rows of the same trace: the profiled run also launches the kernels on other batch sizes (the in-run parity check's
+# 536 positions, the small-batch latency leg), which the aggregated *_kernel_stats.csv averages in; durations below are those
+# of each kernel's most frequent grid -- the timed batch
+trace_files = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+per_dispatch = collections.defaultdict(list)
+if trace_files:
+    for r in csv.DictReader(open(trace_files[0])):
+        per_dispatch[r["Kernel_Name"]].append((r["Grid_Size_X"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+
+
+def full_size_ms(kernel_name):
+    """(average ms, calls) over the dispatches of the kernel's most frequent grid; None without a per-dispatch trace"""
+    rows_ = next((v for k, v in per_dispatch.items() if kernel_name in k), None)
+    if not rows_:
+        return None
+    grid = collections.Counter(g for g, _ in rows_).most_common(1)[0][0]
+    d = [ns for g, ns in rows_ if g == grid]
+    return sum(d) / len(d) / 1e6, len(d)
+
+
 def bench_block(prec):
     return bench if bench["config"]["precision"] == prec else bench.get(prec)
 
@@ -53,12 +73,18 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
             continue
         kern = kern[0]
         avg_ms = own_ms = float(kern["AverageNs"]) / 1e6   # own_ms: this kernel alone (the PMC rows are per dispatch of it)
+        fs = full_size_ms(kname)
+        if fs:
+            avg_ms = own_ms = fs[0]
+            o.write(f"\n(`{kname}`: {fs[1]} dispatches of the timed batch, average {fs[0]:.4f} ms; the stats table above averages "
+                    f"all {kern['Calls']} dispatches, smaller launches included)\n")
         # fp32 at B=4096 runs as 10 whole rounds of 3-board workgroups + a tail launch of 2-board ones (split launch):
         # bench.py's HIP events bracket both, so the per-step kernel time is the sum of the two rows
         tail = [r for r in rows if TAIL_OF.get(prec, "\0") in r["Name"]]
         if tail and abs(int(tail[0]["Calls"]) - int(kern["Calls"])) <= 0.1 * int(kern["Calls"]):
-            o.write(f"\n(split launch: `{kname}` avg {avg_ms:.4f} ms + tail `{TAIL_OF[prec]}` avg {float(tail[0]['AverageNs'])/1e6:.4f} ms per step)\n")
-            avg_ms += float(tail[0]["AverageNs"]) / 1e6
+            tail_ms = (full_size_ms(TAIL_OF[prec]) or (float(tail[0]["AverageNs"]) / 1e6,))[0]
+            o.write(f"\n(split launch: `{kname}` avg {avg_ms:.4f} ms + tail `{TAIL_OF[prec]}` avg {tail_ms:.4f} ms per step)\n")
+            avg_ms += tail_ms
         rf = blk["roofline"]
         o.write(f"\n## {prec}: `{kname}`\n\nbench.py HIP-event kernel time (un-profiled run): {rf['kernel_ms']:.4f} ms "
                 f"(sustained loop {rf.get('sustained_kernel_ms', float('nan')):.4f} ms); rocprofv3 average: {avg_ms:.4f} ms over {kern['Calls']} calls.\n"
