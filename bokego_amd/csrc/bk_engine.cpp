@@ -94,7 +94,10 @@ public:
         if (n > kMaxSlices) return false;
         for (int i = 0; i < n; ++i) done_[i].store(0, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> g(m_);
+            // a worker may still be leaving the previous job's loop (every slice of that job is in place, but the worker has
+            // not yet seen "no slice left"): the job fields change only while nobody reads them
+            std::unique_lock<std::mutex> g(m_);
+            idle_cv_.wait(g, [&] { return active_ == 0; });
             dst_ = static_cast<char*>(dst);
             src_ = static_cast<const char*>(src);
             bytes_ = bytes;
@@ -121,6 +124,7 @@ private:
                 cv_.wait(g, [&] { return quit_ || gen_ != seen; });
                 if (quit_) return;
                 seen = gen_;
+                ++active_;
             }
             for (;;) {
                 const int i = next_.fetch_add(1, std::memory_order_relaxed);
@@ -129,11 +133,17 @@ private:
                 std::memcpy(dst_ + off, src_ + off, std::min(slice_, bytes_ - off));
                 done_[i].store(1, std::memory_order_release);
             }
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --active_;
+            }
+            idle_cv_.notify_one();
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, idle_cv_;
+    int active_ = 0;      // workers inside a job's loop
     bool quit_ = false;
     unsigned long gen_ = 0;
     char* dst_ = nullptr;
