@@ -268,7 +268,7 @@ void features_impl(bk_pos* p, O* out, int fresh) {
 
 extern "C" {
 
-int bk_go_abi_version(void) { return 1; }
+int bk_go_abi_version(void) { return 2; }  // 2: bk_search_params grew (request_tasks, eager_top, request_steps), tree views
 
 void bk_pos_init(bk_pos* p) {
     std::memset(p, 0, sizeof(*p));

@@ -88,6 +88,8 @@ struct Game {
     std::vector<int> path;
     std::vector<int> req_policy, req_value;
     std::vector<int> spec_queue;        // leaves that reached prm.speculate visits and wait for a request with room
+    std::vector<int> spill;             // children of expanded nodes whose value did not fit under prm.request_tasks: they
+                                        // travel with the next requests that have room (or are asked for when selected)
     std::unordered_map<int, std::vector<int>> spec_kids;   // their would-be children's node ids
     Rng rng;
     std::vector<int16_t> moves;
@@ -127,6 +129,35 @@ struct Game {
         return (int)nodes.size() - 1;
     }
 
+    // ---- request size -----------------------------------------------------------------------------------------------------
+    // A request of P policy rows and V value-only rows is 2 P + V network tasks for the engine (a policy row runs both nets).
+    // prm.request_tasks > 0 keeps a request within that many tasks where the search allows it (the fp32 engine gives a board 4
+    // CUs up to 64 tasks and 3 from 65: 104 -> 140 us): values that are wanted but not needed yet wait in `spill` for a later
+    // request.  The networks are pure functions, so WHEN a value is computed never changes the search.
+    int request_tasks() const { return 2 * (int)req_policy.size() + (int)req_value.size(); }
+    // the size the request may grow to at no extra cost: the first step of prm.request_steps that holds what is in it already
+    // (an expansion with unknown priors may have put more than the first step in: it still takes passengers up to ITS step)
+    int ceiling() const {
+        const int cur = std::max(1, request_tasks());
+        for (int st : prm.request_steps)
+            if (st > 0 && cur <= st) return st;
+        return (cur + 255) / 256 * 256;   // beyond the last step: whole rounds of one-CU workgroups
+    }
+    bool fits(int extra_tasks) const { return prm.request_tasks <= 0 || request_tasks() + extra_tasks <= ceiling(); }
+    bool queued_value(int c) const { return std::find(req_value.begin(), req_value.end(), c) != req_value.end(); }
+    // children (node ids) that still lack a value and are not in the request, most promising first when the parent's priors are
+    // known (the search visits high priors first), else in move order
+    std::vector<int> wanting(const std::vector<int>& kids, int parent) const {
+        std::vector<int> w;
+        for (int c : kids)
+            if (!nodes[c].has_value && !queued_value(c)) w.push_back(c);
+        if (prm.request_tasks > 0 && nodes[parent].has_prior) {
+            const double* pr = &priors[nodes[parent].prior_off];
+            std::stable_sort(w.begin(), w.end(), [&](int x, int y) { return pr[nodes[x].mv] > pr[nodes[y].mv]; });
+        }
+        return w;
+    }
+
     // mcts.py:185-192 + the eager evaluation of the new children
     void expand(int id) {
         if (nodes[id].expanded) return;
@@ -141,12 +172,54 @@ struct Game {
         nd.n_kids = n;
         nd.expanded = 1;
         if (!nd.has_prior) req_policy.push_back(id);
-        if (prm.eager)
-            for (int i = 0; i < n; ++i) {
-                const int c = kid_ids[off + i];
-                if (!nodes[c].has_value && std::find(req_value.begin(), req_value.end(), c) == req_value.end())
-                    req_value.push_back(c);
+        const std::vector<int> kidv(kid_ids.begin() + off, kid_ids.begin() + off + n);
+        if (prm.eager_top > 0) {
+            // only the children the search is going to visit: it visits a node's unvisited children in the order of their
+            // priors (PUCT with N = 0, avg = 0) and, measured over 1600-rollout searches, ever visits 4 of ~75 in the median
+            // (10 at the 90th percentile).  With known priors the best eager_top go now; with unknown ones (the policy row is
+            // in this request) nothing does, and the first descent into the node asks for what it needs (request_leaf).
+            if (nodes[id].has_prior) want_best(kidv, id, prm.eager_top);
+        } else if (prm.eager) {
+            // with unknown priors (the policy row travels in this very request) nothing says which child the search wants
+            // first: every child goes now.  With known priors (the node was evaluated ahead) the tail may wait.
+            const bool may_wait = prm.request_tasks > 0 && nodes[id].has_prior;
+            for (int c : wanting(kidv, id)) {
+                if (!may_wait || fits(1)) req_value.push_back(c);
+                else spill.push_back(c);
             }
+        }
+    }
+
+    // request the values of the `k` best-prior children of `parent` that still lack one (parent's priors are known)
+    void want_best(const std::vector<int>& kids, int parent, int k) {
+        const double* pr = &priors[nodes[parent].prior_off];
+        std::vector<int> w;
+        for (int c : kids)
+            if (!nodes[c].has_value && !queued_value(c)) w.push_back(c);
+        if ((int)w.size() > k) {
+            std::partial_sort(w.begin(), w.begin() + k, w.end(), [&](int x, int y) {
+                return pr[nodes[x].mv] > pr[nodes[y].mv] || (pr[nodes[x].mv] == pr[nodes[y].mv] && nodes[x].mv < nodes[y].mv);
+            });
+            w.resize(k);
+        }
+        for (int c : w) req_value.push_back(c);
+    }
+
+    // the rollout's last node needs its value for the backup (mcts.py:151: leaf.value, evaluated on first use).  With
+    // eager_top the request also takes the next-best unevaluated siblings along: where the search got this far down a
+    // node's prior order it tends to go on (all visited children looking bad), and one request then serves the next visits.
+    void request_leaf() {
+        const int leaf = path.back();
+        if (nodes[leaf].has_value || queued_value(leaf)) return;
+        req_value.push_back(leaf);
+        if (prm.eager_top > 0 && path.size() >= 2) {
+            const int parent = path[path.size() - 2];
+            const TNode& pn = nodes[parent];
+            if (pn.has_prior && pn.n_kids > 0) {
+                const std::vector<int> kids(kid_ids.begin() + pn.kids_off, kid_ids.begin() + pn.kids_off + pn.n_kids);
+                want_best(kids, parent, prm.eager_top - 1);
+            }
+        }
     }
 
     int select(int id) const {  // mcts.py:219-234
@@ -169,7 +242,7 @@ struct Game {
 
     // Evaluate ahead (prm.speculate): request id's policy and the values of the children it would get, WITHOUT expanding
     // it -- the children are interned (unlinked nodes) so that the later expand() finds them evaluated.
-    bool speculate(int id) {  // false: does not fit into this request (stays a candidate)
+    bool speculate(int id) {  // false: not (completely) in this request yet: stays a candidate
         if (nodes[id].expanded || nodes[id].terminal || nodes[id].speculated) return true;
         std::vector<int>& cid = spec_kids[id];   // the would-be children, interned once (a candidate may be retried)
         if (cid.empty()) {
@@ -180,17 +253,49 @@ struct Game {
         }
         auto queued = [](const std::vector<int>& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
         const bool want_p = !nodes[id].has_prior && !queued(req_policy, id);
-        int rows = want_p ? 1 : 0;
-        for (int c : cid) rows += (!nodes[c].has_value && !queued(req_value, c)) ? 1 : 0;
-        if ((int)(req_policy.size() + req_value.size()) + rows > prm.speculate_rows) return false;
+        if (prm.eager_top > 0) {
+            // staged: the policy row goes first (2 tasks: it fits any request); once the priors are back, the eager_top
+            // best children -- exactly what expand() would ask for, so that the expansion needs no request of its own
+            if (!nodes[id].has_prior) {
+                if (want_p && (int)(req_policy.size() + req_value.size()) + 1 <= prm.speculate_rows && fits(2)) req_policy.push_back(id);
+                return false;
+            }
+            const size_t before = req_value.size();
+            if ((int)(req_policy.size() + before) + prm.eager_top > prm.speculate_rows || !fits(prm.eager_top)) return false;
+            want_best(cid, id, prm.eager_top);
+            nodes[id].speculated = 1;
+            spec_kids.erase(id);
+            return true;
+        }
+        const std::vector<int> w = wanting(cid, id);
+        const int rows = (want_p ? 1 : 0) + (int)w.size();
+        auto room = [&](int more_rows, int more_tasks) {
+            return (int)(req_policy.size() + req_value.size()) + more_rows <= prm.speculate_rows && fits(more_tasks);
+        };
+        if (prm.request_tasks <= 0) {   // all or nothing: the candidate goes when it fits as a whole
+            if (!room(rows, rows + (want_p ? 1 : 0))) return false;
+        }
+        if (want_p) {
+            if (!room(1, 2)) return false;
+            req_policy.push_back(id);
+        }
+        size_t k = 0;
+        for (; k < w.size() && room(1, 1); ++k) req_value.push_back(w[k]);
+        if (k < w.size()) return false;          // the rest (by prior, once the policy row is back) with a later request
         nodes[id].speculated = 1;
-        if (want_p) req_policy.push_back(id);
-        for (int c : cid)
-            if (!nodes[c].has_value && !queued(req_value, c)) req_value.push_back(c);
         spec_kids.erase(id);
         return true;
     }
-    void add_speculation() {  // a request is going out anyway: let it carry the candidates that fit, most visited first
+    void add_speculation() {  // a request is going out anyway: let it carry what is waiting, then the candidates that fit
+        if (!spill.empty()) {
+            std::vector<int> left;
+            for (int c : spill) {
+                if (nodes[c].has_value || queued_value(c)) continue;
+                if (fits(1)) req_value.push_back(c);
+                else left.push_back(c);
+            }
+            spill.swap(left);
+        }
         std::vector<int> keep;
         for (int id : spec_queue)
             if (!nodes[id].expanded && !nodes[id].speculated && !nodes[id].terminal) keep.push_back(id);
@@ -286,6 +391,10 @@ struct Game {
             if (remap[id] >= 0) nq.push_back(remap[id]);
         spec_queue.swap(nq);
         spec_kids.clear();
+        std::vector<int> ns;
+        for (int id : spill)
+            if (remap[id] >= 0) ns.push_back(remap[id]);
+        spill.swap(ns);
         kid_ids.swap(nk);
         priors.swap(np);
         table.clear();
@@ -356,9 +465,7 @@ struct Game {
                             path.push_back(id);
                         }
                         if (analyze && path.size() > 2) variations[path[1]].assign(path.begin() + 1, path.end());
-                        if (!nodes[path.back()].has_value &&
-                            std::find(req_value.begin(), req_value.end(), path.back()) == req_value.end())
-                            req_value.push_back(path.back());
+                        request_leaf();
                         if (has_request()) { waiting = true; break; }
                         backprop();
                         --remaining;
@@ -437,11 +544,14 @@ void bk_search_params_default(bk_search_params* p) {
     p->sample_plies = 0;
     p->max_turns = 80;
     p->eager = 1;
+    p->eager_top = 0;
     p->komi = 5.5f;
     p->record_visits = 0;
     p->prune = 0;
     p->speculate = 0;
     p->speculate_rows = 128;
+    p->request_tasks = 0;
+    p->request_steps[0] = p->request_steps[1] = p->request_steps[2] = 0;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {
@@ -590,10 +700,12 @@ void bk_pool_set_manual(bk_pool* p, int on) {
     for (auto& g : p->games) g.manual = on != 0;
 }
 
-void bk_pool_set_speculation(bk_pool* p, int speculate, int rows) {   // see bk_search_params.speculate / speculate_rows
+void bk_pool_set_speculation(bk_pool* p, int speculate, int rows, int request_tasks) {   // see bk_search_params
     for (auto& g : p->games) {
         g.prm.speculate = speculate;
         g.prm.speculate_rows = p->row_cap > 0 ? std::min(rows, p->row_cap) : rows;
+        g.prm.request_tasks = request_tasks;
+        g.prm.request_steps[0] = request_tasks;   // the later steps stay as created
     }
 }
 

@@ -20,6 +20,11 @@ import numpy as np
 from . import go, nnet, selfplay
 
 MAX_TURNS = 80
+# children evaluated at an expansion: 0 = every child.  One tree is latency-bound -- a request of 2 tasks and one of 64 cost the
+# same ~100 us round trip -- so what counts is the NUMBER of requests, and evaluating only the best-prior children
+# (bk_search_params.eager_top, what self-play does) doubles it: 1.71 -> 2.45-2.72 ms/move at 4-16 children
+# (profiles/r03_eager_top.txt).  Self-play pools, where the values a game needs later ride in the next batch, use it.
+EAGER_TOP = 0
 
 
 class Position(go.Game):
@@ -147,12 +152,16 @@ class NativeMCTS:
         # launch gives a board 4 CUs up to 64 rows, 3 up to 80 but only 2 from 81, so there a request takes speculative rows
         # only while it stays within 80 (1.91 -> 1.79 ms/move over 80-move games; with 128 or 256 rows it gets SLOWER).
         # Both follow the engine's precision when it is switched later (engine.set_precision), unless given explicitly.
-        self._spec_kw = (kwargs.get("speculate"), kwargs.get("speculate_rows"))
+        # request_tasks (fp32 engines: 64): requests stay within the range in which the cooperative launch gives a board 4 CUs
+        # -- candidates go out in parts, overflowing children of already-evaluated nodes wait for the next request.
+        self._spec_kw = (kwargs.get("speculate"), kwargs.get("speculate_rows"), kwargs.get("request_tasks"))
         self._spec_prec = self._engine_precision()
         spec = self._spec_defaults(self._spec_prec)
         prm = selfplay.search_params(rollouts=0, expand_thresh=self.expand_thresh, c_puct=self.exploration_weight,
                                      noise_weight=self.noise_weight, max_turns=MAX_TURNS, prune=kwargs.get("prune", 0),
-                                     speculate=spec[0], speculate_rows=spec[1])
+                                     speculate=spec[0], speculate_rows=spec[1], request_tasks=spec[2],
+                                     request_steps=kwargs.get("request_steps", (spec[2], 80, 128) if spec[2] == 64 else (spec[2],)))
+        prm.eager_top = kwargs.get("eager_top", EAGER_TOP)
         self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=kwargs.get("cap", 1024), threads=1)
         self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, None)   # Q: simulations are off
         self.children = _ChildrenView(self)
@@ -168,8 +177,8 @@ class NativeMCTS:
         return getattr(getattr(self.evaluator, "engine", None), "precision", None)
 
     def _spec_defaults(self, prec):
-        d = (50, 256) if prec == "f16x2" else (50, 80) if prec == "f32" else (0, 128)
-        return tuple(d[i] if self._spec_kw[i] is None else self._spec_kw[i] for i in (0, 1))
+        d = (50, 256, 0) if prec == "f16x2" else (50, 80, 64) if prec == "f32" else (0, 128, 0)
+        return tuple(d[i] if self._spec_kw[i] is None else self._spec_kw[i] for i in (0, 1, 2))
 
     def _pump(self):
         """Run the native search until it needs nothing more (every outstanding rollout done)."""

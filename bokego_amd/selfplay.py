@@ -30,7 +30,8 @@ class SearchParams(ctypes.Structure):
                 ("noise_weight", ctypes.c_float), ("sample_plies", ctypes.c_int32), ("max_turns", ctypes.c_int32),
                 ("eager", ctypes.c_int32), ("komi", ctypes.c_float), ("record_visits", ctypes.c_int32),
                 ("prune", ctypes.c_int32), ("speculate", ctypes.c_int32),
-                ("speculate_rows", ctypes.c_int32)]
+                ("speculate_rows", ctypes.c_int32), ("request_tasks", ctypes.c_int32), ("eager_top", ctypes.c_int32),
+                ("request_steps", ctypes.c_int32 * 3)]
 
 
 class NodeInfo(ctypes.Structure):
@@ -65,7 +66,7 @@ TREE_SYMBOLS = {
     "bk_pool_play": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int]),
     "bk_pool_set_position": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
     "bk_pool_root_pos": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
-    "bk_pool_set_speculation": (None, [_VP, ctypes.c_int, ctypes.c_int]),
+    "bk_pool_set_speculation": (None, [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "bk_pool_find": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
     "bk_pool_root_id": (ctypes.c_int, [_VP, ctypes.c_int]),
     "bk_pool_node": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NodeInfo), _VP]),
@@ -95,7 +96,11 @@ def search_params(**kw):
     for k, v in kw.items():
         if not hasattr(p, k):
             raise TypeError(f"unknown search parameter {k}")
+        if k == "request_steps":
+            v = (ctypes.c_int32 * 3)(*(list(v) + [0, 0, 0])[:3])
         setattr(p, k, v)
+    if p.request_tasks > 0 and p.request_steps[0] == 0:
+        p.request_steps[0] = p.request_tasks
     return p
 
 
@@ -332,26 +337,40 @@ def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None)
     return out[0], out[1]
 
 
+# self-play: children evaluated at an expansion = the best by prior (bk_search_params.eager_top); in lock-step pools the
+# values a game needs later cost no latency of their own -- they ride in the next batch.  The search visits a node's children
+# in prior order and ever visits 4 of ~75 in the median (10 at the 90th percentile), so evaluating all of them at the expansion
+# (rounds 1-2) was 91 % waste: 3.43 M evaluations per 512-game generation against 0.70 M (4 children) / 0.99 M (8).  Measured on
+# one MI355X, 512 games x 400 rollouts/move, the same 512 games move for move (profiles/r03_eager_top.txt):
+#   fp32   all 8.4 k games/min | 8: 23.2 k | 6: 24.2 k | 4: 25.3 k | 3: 25.9 k | 2: 24.4 k | 1: 22.6 k    (GPU-bound -> host-bound)
+#   f16x2  all 28.1 k          | 4: 35.2 k | 8: 38.4 k | 16: 38.1 k | 24: 35.6 k                          (host-bound throughout)
+EAGER_TOP = {"f32": 4, "f16x2": 8}
+
+
 def shard_game_ids(n_games, rank, world):
     return [g for g in range(n_games) if g % world == rank]
 
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
-              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None):
+              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
     a later job) with the same games coming out; the reference's launcher can only raise when a worker fails
     (bin/selfplay.py:196-199).  The statistics returned are those of the games played here."""
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
+    precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
+    if eager_top is None:
+        eager_top = EAGER_TOP.get(precision, 8)
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
-                        sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits)
+                        sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
+                        eager_top=eager_top)
     if n_pools is None:
         # measured (512 games on one MI355X): with the f16x2 kernel the host is nearly the limit and three rotating pools
         # pay off from ~200 games per rank; with the fp32 kernel the GPU is 3.6x slower per batch, the host has slack,
         # and two larger pools win (7,930 vs 7,857 games/min: fuller batches, less round quantisation)
-        fp32 = getattr(getattr(evaluator, "engine", None), "precision", "f16x2") == "f32"
+        fp32 = precision == "f32"
         n_pools = 3 if (len(gids) >= 192 and not fp32) else 2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     parts = [gids[i::n_pools] for i in range(n_pools)]
@@ -474,6 +493,7 @@ def main():
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
+    ap.add_argument("--eager-top", type=int, default=None, help="children evaluated at an expansion, best priors first (0: all; default 4 in fp32, 8 in f16x2)")
     ap.add_argument("--replay-shard", metavar="RANK/WORLD", default=None,
                     help="re-play the games a failed rank owned (e.g. 3/8: the gids with gid %% 8 == 3) in this process")
     args = ap.parse_args()
@@ -506,7 +526,8 @@ def main():
         gids = shard_game_ids(args.games, r, w)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
-                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)), gids=gids)
+                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)), gids=gids,
+                             eager_top=args.eager_top)
     secs = local["seconds"]
     if world > 1:
         t = torch.tensor([secs], dtype=torch.float64, device="cuda")

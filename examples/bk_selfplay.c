@@ -57,6 +57,12 @@ int main(int argc, char **argv) {
     prm.noise_weight = 0.25f;
     prm.sample_plies = 8;
     prm.prune = 1;
+    /* children evaluated at an expansion: the best by prior (the search visits them in that order and rarely gets past the
+     * first few); what bokego_amd/selfplay.py uses: 4 with the fp32 kernel, 8 with f16x2 */
+    {
+        const char *pe = getenv("BK_PRECISION");
+        prm.eager_top = (pe && strcmp(pe, "f16x2") == 0) ? 8 : 4;
+    }
 
     /* this rank's games, dealt to the pools round-robin */
     slot_t s[NPOOLS];

@@ -54,6 +54,23 @@ typedef struct bk_search_params {
                               "same search" statement holds for networks whose outputs do not depend on the batch a
                               row travels in: the fp32 kernel always, the f16x2 kernel except for a request redone in
                               fp32 after an fp16-range overflow (the rows sharing that request change with it)     */
+    int32_t request_tasks;  /* > 0: keep a request within this many network tasks (2 per policy row, 1 per value-only row)
+                              where the search allows it: a candidate for evaluation ahead goes out in parts (its policy row and
+                              as many children as fit, the rest -- by prior -- with later requests), and the children of a node
+                              whose priors are known wait for a later request when an expansion would overflow.  64 is the range
+                              in which the fp32 engine's cooperative launch gives a board 4 CUs (104 us per request; 140 us
+                              from 65 tasks).  Values are pure functions of the position: the search is unchanged.  0: off  */
+    int32_t eager_top;     /* > 0: instead of every new child (eager), request at an expansion only the values of the eager_top
+                              children with the highest priors -- the ones the search is going to visit first: PUCT orders a
+                              node's unvisited children by prior, and a 1600-rollout search ever visits 4 of a node's ~75
+                              children in the median, 10 at the 90th percentile.  A node whose priors are not known yet sends
+                              its policy row only; any other child is evaluated when a rollout first ends on it, together with
+                              its eager_top - 1 next-best unevaluated siblings.  Same search (values are pure functions of the
+                              position; the reference evaluates every value on first use, mcts.py:393-403), 5-7x fewer
+                              evaluations than eager = 1.  0: off                                                          */
+    int32_t request_steps[3]; /* the sizes at which a request gets dearer, ascending, [0] = request_tasks (fp32 engine: 64, 80,
+                              128 -- 4 / 3 / 2 CUs per board): a request that is already beyond one step -- an expansion whose
+                              priors are not known yet sends all its children -- takes passengers up to the next one     */
 } bk_search_params;
 
 typedef struct bk_game_info {
@@ -101,8 +118,8 @@ int bk_pool_game_visits(const bk_pool *p, int g, int ply, int16_t *moves, int32_
  *   bk_pool_set_position  = set_root(Go_MCTS(board=...))  (clear_board, handicap)
  */
 void bk_pool_set_manual(bk_pool *p, int on);
-/* change bk_search_params.speculate / speculate_rows of every game (e.g. after the engine's precision was switched) */
-void bk_pool_set_speculation(bk_pool *p, int speculate, int rows);
+/* change bk_search_params.speculate / speculate_rows / request_tasks of every game (e.g. after the engine's precision was switched) */
+void bk_pool_set_speculation(bk_pool *p, int speculate, int rows, int request_tasks);
 int bk_pool_add_rollouts(bk_pool *p, int g, int n);
 int bk_pool_choose(bk_pool *p, int g);
 int bk_pool_play(bk_pool *p, int g, int move);

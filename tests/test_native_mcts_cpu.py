@@ -145,11 +145,77 @@ def test_speculation_defaults_follow_the_engines_precision():
             return np.full((n_policy, 81), 1 / 81, np.float32), np.zeros(len(feats), np.float32)
     ev = Ev()
     t = NativeMCTS(Position(), evaluator=ev, cap=128)
-    assert t._spec_defaults("f16x2") == (50, 256) and t._spec_defaults("f32") == (50, 80)
+    assert t._spec_defaults("f16x2") == (50, 256, 0) and t._spec_defaults("f32") == (50, 80, 64)
     t.rollout(300)              # cap=128 < 256 speculative rows: the request is clamped to a collect's capacity, nothing is dropped
     assert t._pool.info(0)["root_N"] == 300
     ev.engine.precision = "f32"
     t.rollout(10)
     assert t._spec_prec == "f32"
-    keep = NativeMCTS(Position(), evaluator=ev, speculate=7, speculate_rows=99)
-    assert keep._spec_defaults("f16x2") == (7, 99)
+    keep = NativeMCTS(Position(), evaluator=ev, speculate=7, speculate_rows=99, request_tasks=33)
+    assert keep._spec_defaults("f16x2") == (7, 99, 33)
+
+
+@pytest.mark.parametrize("prune", [0, 1])
+def test_request_size_cap_does_not_change_the_search(prune):
+    """search_params.request_tasks: requests are kept within N network tasks where the search allows it -- a candidate for
+    evaluation ahead goes out in parts (policy row + the children that fit; the rest, by prior, with later requests) and
+    children of an already-evaluated node wait for the next request when an expansion would overflow.  Same search: chosen
+    moves and every root child's (N, V) after every move equal the uncapped tree's; and the requests really are smaller."""
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+
+    class Sized:
+        def __init__(self):
+            self.tasks, self.ev = [], None
+        def make(self):
+            from bokego_amd import selfplay
+            inner = selfplay.CallableEvaluator(pol, val)
+            outer = self
+            class Ev:
+                def __call__(self, feats, n_policy):
+                    outer.tasks.append(len(feats) + n_policy)
+                    return inner(feats, n_policy)
+            return Ev()
+    sized = {k: Sized() for k in ("plain", "capped", "capped_nospec")}
+    trees = {"plain": NativeMCTS(Position(), evaluator=sized["plain"].make(), expand_thresh=20, speculate=8, speculate_rows=256, prune=prune),
+             "capped": NativeMCTS(Position(), evaluator=sized["capped"].make(), expand_thresh=20, speculate=8, speculate_rows=256,
+                                  request_tasks=40, request_steps=(40, 84, 128), prune=prune),
+             "capped_nospec": NativeMCTS(Position(), evaluator=sized["capped_nospec"].make(), expand_thresh=20, speculate=0,
+                                         request_tasks=40, request_steps=(40, 84, 128), prune=prune)}
+    for ply in range(10):
+        stats = {}
+        for k, t in trees.items():
+            t.rollout(300)
+            stats[k] = t.child_stats()
+            t.choose()
+        assert stats["capped"] == stats["plain"] and stats["capped_nospec"] == stats["plain"], ply
+    assert len({t.root.key() for t in trees.values()}) == 1
+    # in these opening positions nearly every request is an expansion with ~75 children and unknown priors, which sends all of
+    # them: such a request is beyond the first step (40) and takes passengers only up to the next one (84); the uncapped
+    # tree's requests grow to speculate_rows
+    assert max(sized["capped"].tasks) <= 84 and max(sized["plain"].tasks) > 200
+    assert any(n <= 40 for n in sized["capped"].tasks)            # expansions of nodes whose priors were evaluated ahead
+    assert np.mean(sized["capped"].tasks) < 0.5 * np.mean(sized["plain"].tasks)
+
+
+@pytest.mark.parametrize("speculate", [0, 8])
+def test_best_prior_children_only_is_the_same_search_on_one_tree(speculate):
+    """eager_top on the single-tree surface (off by default there: one tree is latency-bound), alone and together with
+    evaluation ahead of expansion, whose candidates then go out staged (policy row first, the K best children once the priors
+    are back): every move and every root child's (N, V) equal the all-children tree's."""
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    mk = lambda k: NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True), expand_thresh=20, speculate=speculate, speculate_rows=256, eager_top=k)  # noqa: E731
+    trees = {k: mk(k) for k in (0, 3, 12)}
+    for ply in range(10):
+        stats = {}
+        for k, t in trees.items():
+            t.rollout(300)
+            stats[k] = t.child_stats()
+            t.choose()
+        assert stats[3] == stats[0] and stats[12] == stats[0], ply
+    info = {k: t._pool.info(0) for k, t in trees.items()}
+    assert info[3]["n_value_evals"] < info[12]["n_value_evals"] < 0.6 * info[0]["n_value_evals"]
+    assert NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True))._pool is not None     # default: every child (EAGER_TOP = 0)

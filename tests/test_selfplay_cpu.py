@@ -250,3 +250,23 @@ def test_a_dead_ranks_shard_can_be_replayed_anywhere():
     assert {**ranks[0]["games"], **replay["games"], **ranks[2]["games"]} == whole["games"]
     empty, named = selfplay.self_play(mk(), gids=[], **KW)
     assert empty["games"] == {} and named["games"] == 0
+
+
+def test_evaluating_only_the_best_prior_children_plays_the_same_games():
+    """bk_search_params.eager_top: an expansion asks for the values of its K best-prior children only (a node whose priors
+    are unknown sends its policy row alone); any other child is evaluated when a rollout first ends on it, with its K - 1
+    next-best siblings.  The games are the same games, move for move and score for score, for every K -- the networks are pure
+    functions, the reference itself evaluates every value on first use (mcts.py:393-403) -- with fewer evaluations."""
+    f = FakeNets()
+    runs = {}
+    for k in (0, 1, 4, 8, 100):
+        ev = selfplay.CallableEvaluator(f.policy, f.value)
+        local, total = selfplay.self_play(ev, eager_top=k, record_visits=1, **KW)
+        runs[k] = (local["games"], local["visits"], total)
+    for k in (1, 4, 8, 100):
+        assert runs[k][0] == runs[0][0] and runs[k][1] == runs[0][1], k          # moves, scores, every ply's root visit counts
+        assert runs[k][2]["plies"] == runs[0][2]["plies"] and runs[k][2]["black_wins"] == runs[0][2]["black_wins"]
+    ev = {k: r[2]["value_evals"] for k, r in runs.items()}
+    assert ev[1] < ev[4] < ev[8] < ev[100] <= ev[0] and ev[4] < 0.6 * ev[0]   # K = 100: a node expanded but never entered again asks for nothing
+    assert runs[1][2]["requests"] > runs[8][2]["requests"] > runs[0][2]["requests"]
+    assert selfplay.EAGER_TOP == {"f32": 4, "f16x2": 8}

@@ -23,6 +23,12 @@ if "BK_SPECULATE" in os.environ:
     kw["speculate"] = int(os.environ["BK_SPECULATE"])
 if "BK_SPECULATE_ROWS" in os.environ:
     kw["speculate_rows"] = int(os.environ["BK_SPECULATE_ROWS"])
+if "BK_REQUEST_TASKS" in os.environ:       # 0: no request-size steps (round-2 behaviour); default on fp32 engines: 64 (steps 64 / 80 / 128)
+    kw["request_tasks"] = int(os.environ["BK_REQUEST_TASKS"])
+if "BK_EAGER_TOP" in os.environ:           # children evaluated at an expansion (0: all)
+    kw["eager_top"] = int(os.environ["BK_EAGER_TOP"])
+if "BK_REQUEST_STEPS" in os.environ:       # e.g. "128,256,512"
+    kw["request_steps"] = tuple(int(v) for v in os.environ["BK_REQUEST_STEPS"].split(","))
 tree = NativeMCTS(mcts.Go_MCTS(), pi, val, **kw)
 ev = tree.evaluator
 sizes, lat = Counter(), []
