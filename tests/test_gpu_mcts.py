@@ -132,11 +132,12 @@ def test_config3_on_native_tree(sds):
     print(f"\nconfig3 native: {dt*1e3:.1f} ms/move, mean batch {ev.positions/ev.batches:.1f}")
 
 
-@pytest.mark.parametrize("precision,kw", [("f16x2", {}), ("f32", {"speculate": 60, "speculate_rows": 256})])
+@pytest.mark.parametrize("precision,kw", [("f16x2", {}), ("f32", {"speculate": 60, "speculate_rows": 256, "request_tasks": 0}), ("f32", {})])
 def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
-    """search_params.speculate (the default of NativeMCTS on an f16x2 engine; forced here for fp32): likely-to-be-expanded
-    leaves are evaluated with requests that go out anyway.  BASELINE config 3 still reproduces the reference trace -- every
-    move, every root-child visit count -- with fewer requests than the plain search."""
+    """search_params.speculate (the default of NativeMCTS on an f16x2 engine; forced here for fp32 in its whole-candidate
+    form; and the fp32 default: candidates staged within the request-size steps 64 / 80 / 128): likely-to-be-expanded leaves
+    are evaluated with requests that go out anyway.  BASELINE config 3 still reproduces the reference trace -- every move,
+    every root-child visit count -- with fewer requests than the plain search."""
     from bokego_amd import nnet
     from bokego_amd.mcts_native import NativeMCTS, Position
     t = json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))["r1600"]
@@ -150,7 +151,10 @@ def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
             assert kids == {int(k): v for k, v in ref["child_N"].items()}
             assert tree.choose().last_move == ref["move"]
     a, p = ahead._pool.info(0), plain._pool.info(0)
-    assert a["n_requests"] < 0.8 * p["n_requests"] and a["n_value_evals"] > p["n_value_evals"]
+    if kw or precision == "f16x2":
+        assert a["n_requests"] < 0.8 * p["n_requests"] and a["n_value_evals"] > p["n_value_evals"]
+    else:       # in the opening's 80-child positions a 64-task request has little room for passengers: fewer, not far fewer
+        assert a["n_requests"] <= p["n_requests"] and a["n_value_evals"] >= p["n_value_evals"]
 
 
 def test_analyze_and_tree_views_on_the_native_tree_on_gpu(sds):
