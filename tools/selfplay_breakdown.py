@@ -1,5 +1,5 @@
 """Where a self-play generation's wall time goes on the host: blocked on the GPU (wait), tree work (deliver +
-the advance half of collect), feature encoding, submit.  usage (GPU box): python tools/selfplay_breakdown.py [pools] [host|gpu]  (where the planes are encoded)"""
+the advance half of collect), feature encoding, submit.  usage (GPU box): python tools/selfplay_breakdown.py [pools] [host|gpu (where the planes are encoded)] [games] [eager_top] [threads]"""
 import os, sys, time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,12 +11,14 @@ from bokego_amd.engine import LeafEngine
 n_pools = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 gpu_encode = (sys.argv[2] if len(sys.argv) > 2 else "gpu") == "gpu"
 n_games = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+eager_top = int(sys.argv[4]) if len(sys.argv) > 4 else 4       # children evaluated per expansion (0: all)
+threads = int(sys.argv[5]) if len(sys.argv) > 5 else None
 g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw")), max_batch=4096)
 ev = selfplay.EngineEvaluator(eng, gpu_encode=gpu_encode)
-prm = selfplay.search_params(rollouts=400, expand_thresh=100, noise_weight=0.25, sample_plies=8, max_turns=80, prune=1)
+prm = selfplay.search_params(rollouts=400, expand_thresh=100, noise_weight=0.25, sample_plies=8, max_turns=80, prune=1, eager_top=eager_top)
 gids = list(range(n_games))
-pools = [selfplay.GamePool([20260 + x for x in gids[i::n_pools]], prm, cap=4096) for i in range(n_pools)]
+pools = [selfplay.GamePool([20260 + x for x in gids[i::n_pools]], prm, cap=4096, threads=threads) for i in range(n_pools)]
 T = dict(wait=0.0, deliver=0.0, collect=0.0, submit=0.0)
 inflight = [None] * n_pools
 live = [True] * n_pools
