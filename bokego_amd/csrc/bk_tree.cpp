@@ -11,8 +11,14 @@
 // pool gathers every game's request into ONE batch of feature planes (policy positions first),
 // the caller evaluates it on the GPU and hands the results back.  Nothing here touches HIP.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -81,7 +87,15 @@ struct Game {
     std::vector<bk_pos> poses;          // parallel to nodes
     std::vector<int> kid_ids;
     std::vector<double> priors;
-    std::unordered_map<uint64_t, std::vector<int>> table;
+    // position -> node id: open addressing over a flat array (power-of-two size, linear probing, -1 = empty).  No per-bucket
+    // allocations: with hundreds of games advancing on a team of threads, the allocator -- a game's memory is freed by
+    // whichever thread advances it next -- was what kept 16 threads from being faster than 4 (profiles/r03_host_tree.txt).
+    std::vector<int> slots;
+    // scratch of prune() / expand() / want_best(), kept for their capacity
+    std::vector<int> sc_remap, sc_order, sc_kids, sc_ids, sc_w;
+    std::vector<TNode> sc_nodes;
+    std::vector<bk_pos> sc_poses;
+    std::vector<double> sc_priors;
     int root = -1;
     State state = S_INIT;
     int remaining = 0;
@@ -109,23 +123,38 @@ struct Game {
         return a.ko == b.ko && a.last_move == b.last_move && ((a.turn ^ b.turn) & 1) == 0 &&
                std::memcmp(a.board, b.board, 81) == 0;
     }
+    static size_t mix(uint64_t h) { return (size_t)((h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull >> 17); }
     int find(const bk_pos& p) const {   // node id of a position, -1 if the tree has never seen it
-        auto it = table.find(key_hash(p));
-        if (it == table.end()) return -1;
-        for (int id : it->second)
+        if (slots.empty()) return -1;
+        const size_t mask = slots.size() - 1;
+        for (size_t i = mix(key_hash(p)) & mask;; i = (i + 1) & mask) {
+            const int id = slots[i];
+            if (id < 0) return -1;
             if (same(poses[id], p)) return id;
-        return -1;
+        }
+    }
+    void table_insert(int id) {
+        const size_t mask = slots.size() - 1;
+        size_t i = mix(key_hash(poses[id])) & mask;
+        while (slots[i] >= 0) i = (i + 1) & mask;
+        slots[i] = id;
+    }
+    void table_rebuild(size_t min_nodes) {   // every node re-entered into a table at most half full
+        size_t cap = 1024;
+        while (cap < 2 * min_nodes) cap <<= 1;
+        slots.assign(cap, -1);
+        for (int i = 0; i < (int)nodes.size(); ++i) table_insert(i);
     }
     int intern(const bk_pos& p) {
-        auto& bucket = table[key_hash(p)];
-        for (int id : bucket)
-            if (same(poses[id], p)) return id;
+        const int have = find(p);
+        if (have >= 0) return have;
+        if (2 * (nodes.size() + 1) > slots.size()) table_rebuild(2 * (nodes.size() + 1));
         TNode n;
         n.mv = p.last_move;
         n.terminal = (p.turn > prm.max_turns || p.last_move == BK_PASS) ? 1 : 0;  // mcts.py:362-364
         nodes.push_back(n);
         poses.push_back(p);
-        bucket.push_back((int)nodes.size() - 1);
+        table_insert((int)nodes.size() - 1);
         return (int)nodes.size() - 1;
     }
 
@@ -172,7 +201,8 @@ struct Game {
         nd.n_kids = n;
         nd.expanded = 1;
         if (!nd.has_prior) req_policy.push_back(id);
-        const std::vector<int> kidv(kid_ids.begin() + off, kid_ids.begin() + off + n);
+        sc_ids.assign(kid_ids.begin() + off, kid_ids.begin() + off + n);
+        const std::vector<int>& kidv = sc_ids;
         if (prm.eager_top > 0) {
             // only the children the search is going to visit: it visits a node's unvisited children in the order of their
             // priors (PUCT with N = 0, avg = 0) and, measured over 1600-rollout searches, ever visits 4 of ~75 in the median
@@ -193,7 +223,8 @@ struct Game {
     // request the values of the `k` best-prior children of `parent` that still lack one (parent's priors are known)
     void want_best(const std::vector<int>& kids, int parent, int k) {
         const double* pr = &priors[nodes[parent].prior_off];
-        std::vector<int> w;
+        std::vector<int>& w = sc_w;
+        w.clear();
         for (int c : kids)
             if (!nodes[c].has_value && !queued_value(c)) w.push_back(c);
         if ((int)w.size() > k) {
@@ -216,8 +247,8 @@ struct Game {
             const int parent = path[path.size() - 2];
             const TNode& pn = nodes[parent];
             if (pn.has_prior && pn.n_kids > 0) {
-                const std::vector<int> kids(kid_ids.begin() + pn.kids_off, kid_ids.begin() + pn.kids_off + pn.n_kids);
-                want_best(kids, parent, prm.eager_top - 1);
+                sc_ids.assign(kid_ids.begin() + pn.kids_off, kid_ids.begin() + pn.kids_off + pn.n_kids);
+                want_best(sc_ids, parent, prm.eager_top - 1);
             }
         }
     }
@@ -354,8 +385,11 @@ struct Game {
         return best;
     }
 
-    void prune() {  // keep only the new root's subtree (bounds memory over a whole game)
-        std::vector<int> remap(nodes.size(), -1), order;
+    void prune() {  // keep only the new root's subtree (bounds memory over a whole game); no allocation once warm
+        std::vector<int>& remap = sc_remap;
+        std::vector<int>& order = sc_order;
+        remap.assign(nodes.size(), -1);
+        order.clear();
         order.push_back(root);
         remap[root] = 0;
         for (size_t i = 0; i < order.size(); ++i) {
@@ -365,12 +399,14 @@ struct Game {
                 if (remap[c] < 0) { remap[c] = (int)order.size(); order.push_back(c); }
             }
         }
-        std::vector<TNode> nn;
-        std::vector<bk_pos> npos;
-        std::vector<int> nk;
-        std::vector<double> np;
-        nn.reserve(order.size());
-        npos.reserve(order.size());
+        std::vector<TNode>& nn = sc_nodes;
+        std::vector<bk_pos>& npos = sc_poses;
+        std::vector<int>& nk = sc_kids;
+        std::vector<double>& np = sc_priors;
+        nn.clear();
+        npos.clear();
+        nk.clear();
+        np.clear();
         for (int old : order) {
             TNode n = nodes[old];
             const int off = (int)nk.size();
@@ -384,21 +420,20 @@ struct Game {
             nn.push_back(n);
             npos.push_back(poses[old]);
         }
-        nodes.swap(nn);
+        nodes.swap(nn);       // the old arrays become next time's scratch
         poses.swap(npos);
-        std::vector<int> nq;
-        for (int id : spec_queue)
-            if (remap[id] >= 0) nq.push_back(remap[id]);
-        spec_queue.swap(nq);
-        spec_kids.clear();
-        std::vector<int> ns;
-        for (int id : spill)
-            if (remap[id] >= 0) ns.push_back(remap[id]);
-        spill.swap(ns);
         kid_ids.swap(nk);
         priors.swap(np);
-        table.clear();
-        for (int i = 0; i < (int)nodes.size(); ++i) table[key_hash(poses[i])].push_back(i);
+        size_t w = 0;
+        for (int id : spec_queue)
+            if (remap[id] >= 0) spec_queue[w++] = remap[id];
+        spec_queue.resize(w);
+        spec_kids.clear();
+        w = 0;
+        for (int id : spill)
+            if (remap[id] >= 0) spill[w++] = remap[id];
+        spill.resize(w);
+        table_rebuild(nodes.size());
         root = 0;
     }
 
@@ -527,6 +562,7 @@ struct Game {
 }  // namespace
 
 struct bk_pool {
+    double t_advance = 0, t_emit = 0, t_deliver = 0;   // seconds spent in the three phases (bk_pool_phase_seconds)
     std::vector<Game> games;
     int row_cap = 0;              // the smallest `cap` a collect was called with: no single request may outgrow it
     std::vector<int> active;      // games included in the last collect, in batch order
@@ -569,6 +605,109 @@ void bk_pool_destroy(bk_pool* p) { delete p; }
 
 namespace {
 
+// ---- the host threads of the pools --------------------------------------------------------------------------------------
+// A pool step is short: a few hundred games advance for some tens of microseconds each, 500-1000 times per second, between
+// two calls from Python.  An OpenMP parallel region per phase spent more time waking its team than working -- on the GPU
+// box's EPYC 9575F 16 threads advanced 256 games only 3.3x faster than one, and 32 games SLOWER than one
+// (profiles/r03_host_tree.txt).  This team keeps its workers spinning for a while after a job (the next one comes within a
+// fraction of a millisecond while a generation runs), lets them sleep when nothing has come for 2 ms, and hands out items
+// one by one from an atomic counter (a game that has to expand a node takes 100x longer than one that does not).
+class Team {
+public:
+    static Team& get() {
+        static Team t;
+        return t;
+    }
+    // fn(i) for i in [0, n) on up to `threads` threads (the caller is one of them); returns when all are done
+    void run(int threads, int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (threads <= 1 || n == 1) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(run_m_);            // pools of different Python threads take turns
+        grow(threads - 1);
+        Job job{&fn, n, threads - 1};
+        job.id = ++last_id_;
+        cur_.store(&job, std::memory_order_release);
+        announced_.store(job.id, std::memory_order_release);     // what sleepers watch (they must not look into `job`)
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> g(m_);
+            cv_.notify_all();
+        }
+        work(job);
+        while (job.done.load(std::memory_order_acquire) < n) cpu_relax();
+        cur_.store(nullptr, std::memory_order_release);
+        while (inside_.load(std::memory_order_acquire) != 0) cpu_relax();   // nobody still looks at `job`
+    }
+    ~Team() {
+        quit_.store(true);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            cv_.notify_all();
+        }
+        for (auto& t : th_) t.join();
+    }
+
+private:
+    struct Job {
+        const std::function<void(int)>* fn;
+        int n, helpers;
+        unsigned long id = 0;
+        std::atomic<int> next{0}, done{0}, joined{0};
+    };
+    static void cpu_relax() { __builtin_ia32_pause(); }
+    static void work(Job& j) {
+        for (;;) {
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) break;
+            (*j.fn)(i);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void grow(int workers) {
+        while ((int)th_.size() < workers && th_.size() < 63) th_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        unsigned long seen = 0;
+        auto idle_since = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (!quit_.load(std::memory_order_relaxed)) {
+            inside_.fetch_add(1, std::memory_order_acq_rel);
+            Job* j = cur_.load(std::memory_order_acquire);
+            if (j && j->id != seen) {
+                seen = j->id;
+                if (j->joined.fetch_add(1, std::memory_order_relaxed) < j->helpers) work(*j);
+                inside_.fetch_sub(1, std::memory_order_acq_rel);
+                idle_since = std::chrono::steady_clock::now();
+                spins = 0;
+                continue;
+            }
+            inside_.fetch_sub(1, std::memory_order_acq_rel);
+            cpu_relax();
+            if (++spins < 2000) continue;                      // ~a few microseconds between looks at the clock
+            spins = 0;
+            if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(2)) continue;
+            {                                                  // nothing for 2 ms: sleep until the next job is announced
+                std::unique_lock<std::mutex> g(m_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait_for(g, std::chrono::milliseconds(50),
+                             [&] { return quit_.load() || announced_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            idle_since = std::chrono::steady_clock::now();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_;
+    std::atomic<Job*> cur_{nullptr};
+    std::atomic<int> inside_{0}, sleepers_{0};
+    std::atomic<unsigned long> announced_{0};
+    std::atomic<bool> quit_{false};
+    unsigned long last_id_ = 0;
+};
+
 // advance every game to its next evaluation request and lay the batch out:
 // [policy nodes of every game ...][value nodes of every game ...]; games whose request does not fit under
 // `cap` keep it for the next collect.  emit(node position, row) writes one row of the batch.
@@ -576,18 +715,20 @@ template <typename Emit>
 int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     const int G = (int)p->games.size();
     std::vector<char> wants(G, 0);
+    const auto t0 = std::chrono::steady_clock::now();
     if (p->row_cap == 0 || cap < p->row_cap) {
         // a request grows by speculative rows up to prm.speculate_rows: never beyond what one collect can take (a request
         // that cannot fit would be skipped for ever: ADVICE r2).  A request without speculation is <= 82 rows <= cap.
         p->row_cap = cap;
         for (auto& gm : p->games) gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
     }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
-    for (int g = 0; g < G; ++g) {
+    Team::get().run(p->threads, G, [&](int g) {
         Game& gm = p->games[g];
         if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
         else if (gm.has_request()) wants[g] = 1;
-    }
+    });
+    const auto t1 = std::chrono::steady_clock::now();
+    p->t_advance += std::chrono::duration<double>(t1 - t0).count();
     p->active.clear();
     p->pol_off.clear();
     p->val_off.clear();
@@ -604,13 +745,13 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
         nval += (int)gm.req_value.size();
     }
     const int A = (int)p->active.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
-    for (int a = 0; a < A; ++a) {
+    Team::get().run(npol + nval >= 64 ? p->threads : 1, A, [&](int a) {
         Game& gm = p->games[p->active[a]];
         for (size_t i = 0; i < gm.req_policy.size(); ++i) emit(&gm.poses[gm.req_policy[i]], (size_t)(p->pol_off[a] + i));
         for (size_t i = 0; i < gm.req_value.size(); ++i) emit(&gm.poses[gm.req_value[i]], (size_t)(npol + p->val_off[a] + i));
         gm.n_requests += 1;
-    }
+    });
+    p->t_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     *n_policy = npol;
     return npol + nval;
 }
@@ -634,11 +775,18 @@ int bk_pool_collect_pos(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
     });
 }
 
+void bk_pool_phase_seconds(const bk_pool* p, double* out3) {   // advance, emit, deliver
+    out3[0] = p->t_advance;
+    out3[1] = p->t_emit;
+    out3[2] = p->t_deliver;
+}
+
 void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
+    const auto t0 = std::chrono::steady_clock::now();
     int npol = 0;
     for (size_t a = 0; a < p->active.size(); ++a) npol += (int)p->games[p->active[a]].req_policy.size();
     const int A = (int)p->active.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads)
+    // a delivery is a few hundred table writes: one thread (a parallel phase cost more than it saved)
     for (int a = 0; a < A; ++a) {
         Game& gm = p->games[p->active[a]];
         for (size_t i = 0; i < gm.req_policy.size(); ++i) {
@@ -651,6 +799,7 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
         gm.req_value.clear();
     }
     p->active.clear();
+    p->t_deliver += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 int bk_pool_n_games(const bk_pool* p) { return (int)p->games.size(); }

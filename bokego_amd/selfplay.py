@@ -54,6 +54,7 @@ TREE_SYMBOLS = {
     "bk_pool_collect": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_pool_collect_pos": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
+    "bk_pool_phase_seconds": (None, [_VP, _VP]),
     "bk_pool_n_games": (ctypes.c_int, [_VP]),
     "bk_pool_n_done": (ctypes.c_int, [_VP]),
     "bk_pool_game_info": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(GameInfo)]),

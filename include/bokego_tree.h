@@ -103,6 +103,9 @@ int bk_pool_collect_pos(bk_pool *p, bk_pos *out, int cap, int *n_policy);
 /* probs: [n_policy][81] (already Categorical-normalised), values: [B], same order as collected */
 void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 
+/* host seconds this pool has spent so far advancing its games (select / expand / backup), writing request rows, and taking
+ * deliveries: out3 = {advance, emit, deliver} (tools/selfplay_breakdown.py) */
+void bk_pool_phase_seconds(const bk_pool *p, double *out3);
 int bk_pool_n_games(const bk_pool *p);
 int bk_pool_n_done(const bk_pool *p);
 int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);
