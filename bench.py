@@ -334,6 +334,7 @@ def launch_plan(n, allowed=None, gpu_nodes=None, node_cpus=None, quota=None, dev
         else:
             cpus = pool[k * len(pool) // len(peers):(k + 1) * len(pool) // len(peers)] or pool
         threads = max(1, min(threads_cap, len(cpus), (quota // n) if quota else len(cpus)))
+        threads = max(1, threads - 4 if threads > 8 else threads)    # the pools' workers spin: leave room for Python and the HIP runtime
         ranks.append({"rank": r, "local_rank": r, "device": devs[r], "numa_node": nd, "cpus": format_cpulist(cpus),
                       "n_cpus": len(cpus), "host_threads": threads})
     return {"world": n, "ranks": ranks, "cpus_allowed": len(allowed), "cgroup_cpu_quota": quota,
@@ -703,6 +704,7 @@ def main():
         # host cores are shared by the ranks: a launch() child got its slice and thread count from the plan, a
         # torch.distributed.run rank sees every CPU and takes 1/world of them (of the cgroup quota when there is one)
         threads = int(os.environ.get("BK_BENCH_HOST_THREADS", 0)) or max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
+        threads = max(1, min(12, threads, (args.selfplay_games // world) // 32 or 1))    # <= one per 16 games of a pool (two pools)
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
               "search": "an expansion evaluates its best-prior children only (bk_search_params.eager_top), the rest when a rollout "

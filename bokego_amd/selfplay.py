@@ -105,6 +105,21 @@ def search_params(**kw):
     return p
 
 
+def default_threads(n_games):
+    """Host threads of a pool: the team's workers spin between the steps of a generation (bk_tree.cpp, Team), so they must
+    fit the CPUs this process really owns -- the cgroup quota, not the affinity mask -- with room left for the Python thread
+    and the HIP runtime's: 12 of a 16-CPU share (16 threads: 25.6 k games/min, erratic, against 27.6 k with 12), and no more
+    than one per 16 games (64 games: 4 threads 18.7 k games/min, 16 threads 13.7 k; profiles/r03_eager_top.txt)."""
+    own = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            own = min(own, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(12, own - 4 if own > 8 else own // 2, max(1, n_games // 16)))
+
+
 class GamePool:
     """Lock-step pool of independent self-play games on the native tree core."""
 
@@ -113,7 +128,7 @@ class GamePool:
         self.seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         self.n = len(self.seeds)
         self.cap = max(int(cap), 82)
-        threads = threads or max(1, min(16, len(os.sched_getaffinity(0))))
+        threads = threads or default_threads(self.n)
         self._h = self._lib.bk_pool_create(self.n, ctypes.byref(params), self.seeds.ctypes.data, int(threads))
         if not self._h:
             raise RuntimeError("bk_pool_create failed")
@@ -345,7 +360,9 @@ def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None)
 # one MI355X, 512 games x 400 rollouts/move, the same 512 games move for move (profiles/r03_eager_top.txt):
 #   fp32   all 8.4 k games/min | 8: 23.2 k | 6: 24.2 k | 4: 25.3 k | 3: 25.9 k | 2: 24.4 k | 1: 22.6 k    (GPU-bound -> host-bound)
 #   f16x2  all 28.1 k          | 4: 35.2 k | 8: 38.4 k | 16: 38.1 k | 24: 35.6 k                          (host-bound throughout)
-EAGER_TOP = {"f32": 4, "f16x2": 8}
+# and with the host side of the pools reworked (worker team, flat position table, 12 threads): fp32 27.6 k (GPU-bound again: one
+# round of workgroups per step), f16x2 59.3 k at 4 children and two pools (8 children / three pools: 53.0 k).
+EAGER_TOP = {"f32": 4, "f16x2": 4}
 
 
 def shard_game_ids(n_games, rank, world):
@@ -368,11 +385,10 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
                         eager_top=eager_top)
     if n_pools is None:
-        # measured (512 games on one MI355X): with the f16x2 kernel the host is nearly the limit and three rotating pools
-        # pay off from ~200 games per rank; with the fp32 kernel the GPU is 3.6x slower per batch, the host has slack,
-        # and two larger pools win (7,930 vs 7,857 games/min: fuller batches, less round quantisation)
-        fp32 = precision == "f32"
-        n_pools = 3 if (len(gids) >= 192 and not fp32) else 2
+        # two pools: the host advances one while the GPU evaluates the other's batch.  (Rounds 1-2, every child evaluated: three
+        # pools paid off for f16x2 from ~200 games per rank; with the best-prior children only, batches are 5x smaller and
+        # two fuller ones win in both precisions: f16x2 59.3 k against 51.5 k games/min, fp32 25.9 k against 19.7 k)
+        n_pools = 2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     parts = [gids[i::n_pools] for i in range(n_pools)]
     pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
@@ -494,7 +510,7 @@ def main():
     ap.add_argument("--out", default=None, help="directory for this rank's records (SGF per game + games.json with visit counts)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
-    ap.add_argument("--eager-top", type=int, default=None, help="children evaluated at an expansion, best priors first (0: all; default 4 in fp32, 8 in f16x2)")
+    ap.add_argument("--eager-top", type=int, default=None, help="children evaluated at an expansion, best priors first (0: all; default 4)")
     ap.add_argument("--replay-shard", metavar="RANK/WORLD", default=None,
                     help="re-play the games a failed rank owned (e.g. 3/8: the gids with gid %% 8 == 3) in this process")
     args = ap.parse_args()

@@ -58,10 +58,11 @@ int main(int argc, char **argv) {
     prm.sample_plies = 8;
     prm.prune = 1;
     /* children evaluated at an expansion: the best by prior (the search visits them in that order and rarely gets past the
-     * first few); what bokego_amd/selfplay.py uses: 4 with the fp32 kernel, 8 with f16x2 */
+     * first few); what bokego_amd/selfplay.py uses */
     {
         const char *pe = getenv("BK_PRECISION");
-        prm.eager_top = (pe && strcmp(pe, "f16x2") == 0) ? 8 : 4;
+        (void)pe;
+        prm.eager_top = 4;
     }
 
     /* this rank's games, dealt to the pools round-robin */
@@ -75,7 +76,10 @@ int main(int argc, char **argv) {
         uint64_t *ps = malloc(sizeof(uint64_t) * (mine / npools + 1));
         int k = 0;
         for (int j = i; j < mine; j += npools) ps[k++] = seeds[j];
-        s[i].pool = bk_pool_create(k, &prm, ps, ncpu < 16 ? (int)ncpu : 16);
+        /* the pools' worker threads spin between steps: 12 of a 16-CPU share, and no more than one per 16 games */
+        int threads = ncpu > 8 ? (ncpu - 4 < 12 ? (int)ncpu - 4 : 12) : (int)ncpu / 2;
+        if (threads > k / 16) threads = k / 16;
+        s[i].pool = bk_pool_create(k, &prm, ps, threads < 1 ? 1 : threads);
         s[i].n_games = k;
         s[i].recs = malloc(sizeof(bk_pos) * CAP);
         s[i].probs = malloc(sizeof(float) * 81 * CAP);

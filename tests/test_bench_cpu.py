@@ -53,7 +53,7 @@ def test_launch_plan_splits_whole_cores_by_numa_node():
     seen = set()
     for r in plan["ranks"]:
         cpus = bench.parse_cpulist(r["cpus"])
-        assert len(cpus) == 32 and r["host_threads"] == 16 and r["device"] == r["rank"] == r["local_rank"]
+        assert len(cpus) == 32 and r["host_threads"] == 12 and r["device"] == r["rank"] == r["local_rank"]
         assert set(cpus) <= set(node_cpus[r["numa_node"]]) and r["numa_node"] == (0 if r["rank"] < 4 else 1)
         assert {c % 128 for c in cpus} == {c % 128 for c in cpus if c < 128}, "SMT siblings stay with one rank"
         assert not seen & set(cpus)
