@@ -565,6 +565,7 @@ struct bk_pool {
     double t_advance = 0, t_emit = 0, t_deliver = 0;   // seconds spent in the three phases (bk_pool_phase_seconds)
     std::vector<Game> games;
     int row_cap = 0;              // the smallest `cap` a collect was called with: no single request may outgrow it
+    int task_cap = 0, first = 0;  // bk_pool_set_task_cap; the game that goes first into the next batch
     std::vector<int> active;      // games included in the last collect, in batch order
     std::vector<int> pol_off, val_off;
     int threads = 1;
@@ -733,17 +734,27 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     p->pol_off.clear();
     p->val_off.clear();
     int npol = 0, nval = 0;
-    for (int g = 0; g < G; ++g) {
+    // task_cap: the batch stops growing where the engine's launch would need another round of workgroups (bk_pool_set_task_cap);
+    // a game whose request does not fit keeps it and goes first next time
+    const int start = p->task_cap > 0 ? p->first % G : 0;
+    int first_left = -1;
+    for (int k = 0; k < G; ++k) {
+        const int g = start + k < G ? start + k : start + k - G;
         if (!wants[g]) continue;
         Game& gm = p->games[g];
         const int need = (int)(gm.req_policy.size() + gm.req_value.size());
-        if (npol + nval + need > cap) continue;
+        const bool over = p->task_cap > 0 && !p->active.empty() && 2 * npol + nval + gm.request_tasks() > p->task_cap;
+        if (npol + nval + need > cap || over) {
+            if (first_left < 0) first_left = g;
+            continue;
+        }
         p->active.push_back(g);
         p->pol_off.push_back(npol);
         p->val_off.push_back(nval);
         npol += (int)gm.req_policy.size();
         nval += (int)gm.req_value.size();
     }
+    if (first_left >= 0) p->first = first_left;
     const int A = (int)p->active.size();
     Team::get().run(npol + nval >= 64 ? p->threads : 1, A, [&](int a) {
         Game& gm = p->games[p->active[a]];
@@ -848,6 +859,8 @@ int bk_pool_game_visits(const bk_pool* p, int g, int ply, int16_t* moves, int32_
 void bk_pool_set_manual(bk_pool* p, int on) {
     for (auto& g : p->games) g.manual = on != 0;
 }
+
+void bk_pool_set_task_cap(bk_pool* p, int tasks) { p->task_cap = tasks > 0 ? tasks : 0; }
 
 void bk_pool_set_speculation(bk_pool* p, int speculate, int rows, int request_tasks) {   // see bk_search_params
     for (auto& g : p->games) {

@@ -55,6 +55,7 @@ TREE_SYMBOLS = {
     "bk_pool_collect_pos": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
     "bk_pool_phase_seconds": (None, [_VP, _VP]),
+    "bk_pool_set_task_cap": (None, [_VP, ctypes.c_int]),
     "bk_pool_n_games": (ctypes.c_int, [_VP]),
     "bk_pool_n_done": (ctypes.c_int, [_VP]),
     "bk_pool_game_info": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(GameInfo)]),
@@ -141,6 +142,10 @@ class GamePool:
 
     def __del__(self):
         self.close()
+
+    def set_task_cap(self, tasks):
+        """Soft limit of a batch in network tasks (bk_pool_set_task_cap); 0: none."""
+        self._lib.bk_pool_set_task_cap(self._h, int(tasks))
 
     def collect(self):
         """-> (uint8 feats [B,27,9,9] view, n_policy); B == 0 when every game is finished."""
@@ -371,7 +376,7 @@ def shard_game_ids(n_games, rank, world):
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
-              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None):
+              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
@@ -392,6 +397,14 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     parts = [gids[i::n_pools] for i in range(n_pools)]
     pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
+    if task_cap is None:
+        # fp32 engine: a step's launch costs whole rounds of 3-board workgroups (0.75 ms per 768 tasks on 256 CUs), and a batch
+        # just over a round pays for two: hold batches to the whole number of rounds nearest to what the pool's games ask for
+        # (~3 tasks per game and step with 4 children per expansion).  f16x2 steps are host-bound: no limit.
+        per_round = 3 * getattr(getattr(evaluator, "engine", None), "n_cu", 256)
+        task_cap = per_round * max(1, round(3.0 * max(len(part) for part in parts) / per_round)) if (precision == "f32" and eager_top) else 0
+    for pool in pools:
+        pool.set_task_cap(task_cap)
     t0 = time.perf_counter()
     steps = run_pools(pools, evaluator, progress)
     dt = time.perf_counter() - t0
@@ -511,6 +524,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     ap.add_argument("--eager-top", type=int, default=None, help="children evaluated at an expansion, best priors first (0: all; default 4)")
+    ap.add_argument("--task-cap", type=int, default=None, help="soft limit of a batch in network tasks (default: whole rounds of workgroups for fp32, none for f16x2; 0: none)")
     ap.add_argument("--replay-shard", metavar="RANK/WORLD", default=None,
                     help="re-play the games a failed rank owned (e.g. 3/8: the gids with gid %% 8 == 3) in this process")
     args = ap.parse_args()
@@ -544,7 +558,7 @@ def main():
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
                              reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)), gids=gids,
-                             eager_top=args.eager_top)
+                             eager_top=args.eager_top, task_cap=args.task_cap)
     secs = local["seconds"]
     if world > 1:
         t = torch.tensor([secs], dtype=torch.float64, device="cuda")

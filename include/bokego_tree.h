@@ -100,6 +100,11 @@ int bk_pool_collect(bk_pool *p, uint8_t *feats, int cap, int *n_policy);
  * to out[B]; the planes are a pure function of the record (bk_pos_features_u8 on it gives exactly what
  * bk_pool_collect would have written) and are computed on the GPU by bk_submit_positions. */
 int bk_pool_collect_pos(bk_pool *p, bk_pos *out, int cap, int *n_policy);
+/* Soft limit of a batch in network tasks (2 per policy row, 1 per value-only row; 0 = none): the batch stops taking games'
+ * requests where one more would push it over -- e.g. 768 = one round of 3-board workgroups on 256 CUs, beyond which the fp32
+ * engine's launch takes 1.1 instead of 0.75 ms.  A game left out keeps its request and goes first into the next batch; what a
+ * game computes does not depend on the batch it travels in. */
+void bk_pool_set_task_cap(bk_pool *p, int tasks);
 /* probs: [n_policy][81] (already Categorical-normalised), values: [B], same order as collected */
 void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 

@@ -270,3 +270,20 @@ def test_evaluating_only_the_best_prior_children_plays_the_same_games():
     assert ev[1] < ev[4] < ev[8] < ev[100] <= ev[0] and ev[4] < 0.6 * ev[0]   # K = 100: a node expanded but never entered again asks for nothing
     assert runs[1][2]["requests"] > runs[8][2]["requests"] > runs[0][2]["requests"]
     assert selfplay.EAGER_TOP == {"f32": 4, "f16x2": 4}
+
+
+def test_a_task_cap_on_the_batches_only_changes_how_games_are_grouped():
+    """bk_pool_set_task_cap: batches stop growing at N network tasks (the fp32 engine pays per whole round of workgroups);
+    games left out keep their request and go first next time.  Same games, same evaluations, more (smaller) batches."""
+    f = FakeNets()
+    out = {}
+    for cap in (0, 9, 3):
+        ev = selfplay.CallableEvaluator(f.policy, f.value)
+        local, total = selfplay.self_play(ev, task_cap=cap, n_pools=1, **KW)
+        out[cap] = (local["games"], total["value_evals"], total["plies"], ev.batches)
+    assert out[9][:3] == out[0][:3] and out[3][:3] == out[0][:3]
+    assert out[3][3] > out[9][3] > out[0][3]
+    # the default: whole rounds for an fp32 engine, none otherwise (a CallableEvaluator has no engine: none)
+    pool = selfplay.GamePool([1, 2, 3], selfplay.search_params(rollouts=10, max_turns=3), cap=256, threads=1)
+    pool.set_task_cap(768)
+    pool.close()
