@@ -20,7 +20,9 @@ The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the refe
                 also checks a sample of the timed workload output against the CPU oracle it has loaded anyway)
   f16x2         the opt-in split-fp16 variant, same measurements, priced against the f16 MFMA peak
   roofline      bound = MFMA: SURVEY 8d's 266,838,272 algorithmic FLOP per leaf-eval over the dense MFMA peak of the
-                dtype the matrix unit executes; kernel time from HIP events on the launch stream
+                dtype the matrix unit executes; kernel time from HIP events on the launch stream; `traffic`, `mfma_busy`,
+                `effective_clock_ghz` and the executed MFMA FLOP from rocprofv3 --pmc passes made IN THIS RUN over a child
+                process that issues the same launch (N=1; --no-live-pmc or a missing rocprofv3: the committed summary, named)
   cpu_baseline  the reference's CPU path restated (oracle/torch_ref.py: the same torch ops on the host's cores, and
                 oracle/nnet_ref.c, the plain-C port) on a bounded sample of the same workload
   selfplay      secondary, outside the timed region: BASELINE configs[3] (512 self-play games sharded over the
@@ -502,16 +504,103 @@ def measure(eng, x, steps, warmup, barrier, reduce_max, sustain_s, torch):
             "p10_p50_p90": [float(np.percentile(each, q)) for q in (10, 50, 90)]}
 
 
-def roofline(precision, batch, kern_ms, sust, spread):
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("GRBM_GUI_ACTIVE",),
+              ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVES"))
+
+
+def live_counters(batch, precision, timeout_s=150):
+    """The hardware counters of the timed launch, measured in THIS run: one rocprofv3 --pmc pass per counter group (separate
+    passes, as MI355X_MICROARCH.md's HBM section prescribes) around a child process -- `python3 bench.py --pmc-child`, started
+    after the timed region -- that issues the same B-position launch a few times.  Per step (= every launch of the step: the
+    3-board rounds and the 2-board tail) -> HBM-side bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE
+    correction), MFMA-pipe occupancy, effective clock, executed fp32-MFMA FLOP.  None when rocprofv3 is not there or a pass
+    fails: the caller then falls back to the committed PMC summary and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    kern = "bk_leaf_eval_f16_kernel" if precision == "f16x2" else "bk_leaf_eval_kernel"
+    tot, t0 = {}, time.perf_counter()
+    for ctrs in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                "--pmc-child", "--batch", str(batch), "--precision", precision],
+                               capture_output=True, text=True, timeout=timeout_s, cwd=REPO, env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            rows = [x for f in files for x in csv.DictReader(open(f)) if kern in x["Kernel_Name"]]
+            steps = {}                                   # dispatches of one step share nothing but order: group by grid size
+            for x in rows:
+                steps.setdefault((x["Kernel_Name"], x["Grid_Size"]), []).append(x)
+            n = max((len(v) for v in steps.values()), default=0)
+            if n == 0:
+                return None
+            for (name, grid), v in steps.items():
+                if len(v) < n:                           # a launch that is not part of every step
+                    continue
+                per = {}
+                for x in v:
+                    per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
+                for c, vals in per.items():
+                    tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
+                    if c == "GRBM_GUI_ACTIVE":
+                        tot["_ns"] = tot.get("_ns", 0.0) + sum(b for _, b in vals) / len(vals)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {"source": f"measured in this run: rocprofv3 --pmc, {len(PMC_PASSES)} separate passes over a child process issuing the same "
+                     f"launch ({time.perf_counter() - t0:.0f} s)", "counters_per_step": {k: v for k, v in tot.items() if not k.startswith("_")}}
+    if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+        out["hbm_traffic_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
+    if tot.get("GRBM_GUI_ACTIVE") and tot.get("_ns"):
+        out["effective_clock_ghz"] = tot["GRBM_GUI_ACTIVE"] / 8 / tot["_ns"]
+        if tot.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            out["mfma_busy"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (tot["GRBM_GUI_ACTIVE"] / 8)
+    if tot.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
+        out["executed_mfma_flop_per_launch"] = tot["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
+    return out
+
+
+def pmc_child(args):
+    """What the profiled child does: the timed launch, a few times, nothing else."""
+    import torch
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    g = os.path.join(REPO, "tests", "golden")
+    eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw")), device_id=0,
+                     max_batch=args.batch, precision=args.precision)
+    x = torch.from_numpy(make_workload(args.batch, 0)[0]).cuda()
+    for _ in range(8):
+        eng.eval_device(x, logits=True, probs=True, value=True)
+    torch.cuda.synchronize()
+    eng.close()
+    return 0
+
+
+def roofline(precision, batch, kern_ms, sust, spread, live=None):
     f16 = precision == "f16x2"
     peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
     achieved = batch * FLOP_PER_LEAF / (kern_ms * 1e-3) / 1e12
-    pmc = measured_counters(batch, precision) or {}
+    pmc = dict(measured_counters(batch, precision) or {})
+    file_source = pmc.get("source")
+    if live:                                          # measured in this run: replaces what the committed summary says
+        pmc.update({k: v for k, v in live.items() if v is not None})
+        if live.get("executed_mfma_flop_per_launch") and precision == "f32":
+            pmc.pop("executed_mfma_flop_per_workgroup", None)
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "traffic_source": pmc.get("source"), "kernel": KERNEL[precision],
          "kernel_ms": kern_ms, "kernel_ms_isolated_p10_p50_p90": spread,
          "algorithmic_flop_per_launch": batch * FLOP_PER_LEAF, "algorithmic_hbm_bytes_per_launch": batch * BYTES_PER_LEAF,
-         "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"), "pmc_source": pmc.get("source")}
+         "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"), "pmc_source": pmc.get("source"),
+         "pmc_file_fallback": None if live else file_source}
+    if live and live.get("executed_mfma_flop_per_launch"):
+        r["pmc_executed_mfma_flop_per_launch"] = live["executed_mfma_flop_per_launch"]
     if f16:
         # nominal: 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC, before padding and skipped zero-halo taps
         # (executed_mfma_tflops below is the counted figure for 3-board workgroups)
@@ -551,6 +640,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
                     help="arithmetic of the HEADLINE (default f32 = the reference's width; f16x2 only for profiling that variant)")
     ap.add_argument("--selfplay-games", type=int, default=512, help="games of the secondary configs[3] measurement (512 = the config; tests use fewer)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes (roofline.traffic etc. then come from the committed summary)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plan", action="store_true", help="print the N-rank launch plan (devices, CPU slices, port) and exit; no GPU call")
     args = ap.parse_args()
 
@@ -564,6 +655,8 @@ def main():
 
     if os.environ.get("BK_BENCH_LAUNCH_SELFTEST"):
         sys.exit(launch_selftest(args))
+    if args.pmc_child:
+        sys.exit(pmc_child(args))
 
     import torch
 
@@ -725,6 +818,10 @@ def main():
         sp["games_per_min"] = sp[args.precision]["games_per_min"]
         sp["stats_allreduce_ms"] = sp[args.precision]["stats_allreduce_ms"]
 
+    live = None
+    if rank == 0 and world == 1 and not args.no_live_pmc:
+        live = live_counters(args.batch, args.precision)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pw, vw, x_host, head_logits, head_values)
@@ -746,7 +843,7 @@ def main():
                        "parity_workload_sample": cpu["timed_output_vs_oracle_sample"] if cpu else None,
                        "sharding": f"positions x{world}, no data-path collective"},
             "sustained": head["sustained"],
-            "roofline": roofline(args.precision, args.batch, head["kernel_ms"], head["sustained"], head["p10_p50_p90"]),
+            "roofline": roofline(args.precision, args.batch, head["kernel_ms"], head["sustained"], head["p10_p50_p90"], live),
             other_name: other,
             "cpu_baseline": cpu,
             "selfplay": sp,

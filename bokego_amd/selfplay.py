@@ -401,8 +401,10 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         # fp32 engine: a step's launch costs whole rounds of 3-board workgroups (0.75 ms per 768 tasks on 256 CUs), and a batch
         # just over a round pays for two: hold batches to the whole number of rounds nearest to what the pool's games ask for
         # (~3 tasks per game and step with 4 children per expansion).  f16x2 steps are host-bound: no limit.
+        # (minus 4: policy rows and value rows are rounded up to whole 3-board workgroups separately, and 257 workgroups are
+        # two rounds -- rocprofv3 showed 605 of 1,160 launches at exactly 768 tasks taking the 1.0 ms three-round one-board form)
         per_round = 3 * getattr(getattr(evaluator, "engine", None), "n_cu", 256)
-        task_cap = per_round * max(1, round(3.0 * max(len(part) for part in parts) / per_round)) if (precision == "f32" and eager_top) else 0
+        task_cap = per_round * max(1, round(3.0 * max(len(part) for part in parts) / per_round)) - 4 if (precision == "f32" and eager_top) else 0
     for pool in pools:
         pool.set_task_cap(task_cap)
     t0 = time.perf_counter()
