@@ -366,8 +366,10 @@ def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None)
 #   fp32   all 8.4 k games/min | 8: 23.2 k | 6: 24.2 k | 4: 25.3 k | 3: 25.9 k | 2: 24.4 k | 1: 22.6 k    (GPU-bound -> host-bound)
 #   f16x2  all 28.1 k          | 4: 35.2 k | 8: 38.4 k | 16: 38.1 k | 24: 35.6 k                          (host-bound throughout)
 # and with the host side of the pools reworked (worker team, flat position table, 12 threads): fp32 27.6 k (GPU-bound again: one
-# round of workgroups per step), f16x2 59.3 k at 4 children and two pools (8 children / three pools: 53.0 k).
-EAGER_TOP = {"f32": 4, "f16x2": 4}
+# round of workgroups per step), f16x2 59.3 k at 4 children and two pools (8 children / three pools: 53.0 k); and with fp32
+# batches held to whole rounds of workgroups (task_cap below): fp32 3: 32.3 k | 4: 32.9 k | 5: 30.8 k | 6: 28.8 k | 8: 25.2 k;
+# f16x2 3: 55.4 k | 4: 58.9 k | 6: 62.6 k.
+EAGER_TOP = {"f32": 4, "f16x2": 6}
 
 
 def shard_game_ids(n_games, rank, world):

@@ -61,8 +61,7 @@ int main(int argc, char **argv) {
      * first few); what bokego_amd/selfplay.py uses */
     {
         const char *pe = getenv("BK_PRECISION");
-        (void)pe;
-        prm.eager_top = 4;
+        prm.eager_top = (pe && strcmp(pe, "f16x2") == 0) ? 6 : 4;
     }
 
     /* this rank's games, dealt to the pools round-robin */

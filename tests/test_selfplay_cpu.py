@@ -269,7 +269,7 @@ def test_evaluating_only_the_best_prior_children_plays_the_same_games():
     ev = {k: r[2]["value_evals"] for k, r in runs.items()}
     assert ev[1] < ev[4] < ev[8] < ev[100] <= ev[0] and ev[4] < 0.6 * ev[0]   # K = 100: a node expanded but never entered again asks for nothing
     assert runs[1][2]["requests"] > runs[8][2]["requests"] > runs[0][2]["requests"]
-    assert selfplay.EAGER_TOP == {"f32": 4, "f16x2": 4}
+    assert selfplay.EAGER_TOP == {"f32": 4, "f16x2": 6}
 
 
 def test_a_task_cap_on_the_batches_only_changes_how_games_are_grouped():
