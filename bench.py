@@ -520,7 +520,7 @@ def live_counters(batch, precision, timeout_s=150):
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3")
-    if exe is None:
+    if exe is None or under_profiler():
         return None
     kern = "bk_leaf_eval_f16_kernel" if precision == "f16x2" else "bk_leaf_eval_kernel"
     tot, t0 = {}, time.perf_counter()
@@ -565,6 +565,12 @@ def live_counters(batch, precision, timeout_s=150):
     if tot.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
         out["executed_mfma_flop_per_launch"] = tot["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
     return out
+
+
+def under_profiler():
+    """True when this process itself runs under rocprofv3 / rocprofiler (tools/profile_bench.sh): no profiler inside a profiler."""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+        any(k.startswith("ROCPROF") for k in os.environ)
 
 
 def pmc_child(args):
