@@ -69,7 +69,8 @@ int main(int argc, char **argv) {
     uint64_t *seeds = malloc(sizeof(uint64_t) * (n_games + 1));
     int mine = 0;
     for (int g = rank; g < n_games; g += world) seeds[mine++] = 20260 + (uint64_t)g;
-    const int npools = mine >= 192 ? 3 : (mine >= 2 ? 2 : 1);
+    /* two pools: the host advances one while the GPU evaluates the other's batch */
+    const int npools = mine >= 2 ? 2 : 1;
     const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     for (int i = 0; i < npools; ++i) {
         uint64_t *ps = malloc(sizeof(uint64_t) * (mine / npools + 1));
@@ -79,6 +80,15 @@ int main(int argc, char **argv) {
         int threads = ncpu > 8 ? (ncpu - 4 < 12 ? (int)ncpu - 4 : 12) : (int)ncpu / 2;
         if (threads > k / 16) threads = k / 16;
         s[i].pool = bk_pool_create(k, &prm, ps, threads < 1 ? 1 : threads);
+        /* fp32 engine: a launch costs whole rounds of 3-board workgroups (256 CUs x 3 tasks); hold the batches to the whole
+         * number of rounds nearest to what the pool asks for (~3 tasks per game and step), minus the per-net rounding */
+        {
+            const char *pe2 = getenv("BK_PRECISION");
+            if (!(pe2 && strcmp(pe2, "f16x2") == 0)) {
+                int rounds = (3 * k + 384) / 768;
+                bk_pool_set_task_cap(s[i].pool, 768 * (rounds < 1 ? 1 : rounds) - 4);
+            }
+        }
         s[i].n_games = k;
         s[i].recs = malloc(sizeof(bk_pos) * CAP);
         s[i].probs = malloc(sizeof(float) * 81 * CAP);
