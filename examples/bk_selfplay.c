@@ -179,11 +179,18 @@ int main(int argc, char **argv) {
         reduce_ms = (now() - t1) * 1e3;
         bk_comm_destroy(c);
     }
+    double host[3] = {0, 0, 0};       /* seconds the pools spent advancing games / writing request rows / taking deliveries */
+    for (int i = 0; i < npools; ++i) {
+        double t[3];
+        bk_pool_phase_seconds(s[i].pool, t);
+        for (int k = 0; k < 3; ++k) host[k] += t[k];
+    }
     if (rank == 0)
         printf("{\"games\": %.0f, \"local_games\": %d, \"seconds\": %.4f, \"local_games_per_min\": %.0f, \"steps\": %ld, \"mean_batch\": %.0f, "
                "\"plies\": %.0f, \"black_wins\": %.0f, \"value_evals\": %.0f, \"policy_evals\": %.0f, \"allreduce_ms\": %.3f, "
-               "\"moves_checksum\": \"%016llx\"}\n",
-               st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms, check);
+               "\"host_advance_s\": %.3f, \"host_emit_s\": %.3f, \"host_deliver_s\": %.3f, \"moves_checksum\": \"%016llx\"}\n",
+               st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms,
+               host[0], host[1], host[2], check);
     for (int i = 0; i < npools; ++i) bk_pool_destroy(s[i].pool);
     bk_engine_destroy(e);
     return 0;
