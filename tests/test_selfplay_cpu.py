@@ -100,7 +100,8 @@ def test_games_do_not_depend_on_world_size_or_pool_split():
     g1, s1 = _run_world(1, **KW)
     g2, s2 = _run_world(2, **KW)
     g4, s4 = _run_world(4, n_pools=1, **KW)
-    assert g1 == g2 == g4 and np.array_equal(s1, s2) and np.array_equal(s1, s4)
+    g8, s8 = _run_world(8, **KW)                 # more ranks than games: one rank plays nothing, the sums still add up
+    assert g1 == g2 == g4 == g8 and np.array_equal(s1, s2) and np.array_equal(s1, s4) and np.array_equal(s1, s8)
     assert len({tuple(g["moves"]) for g in g1.values()}) > 1      # seeds really differ per game
     assert all(len(g["moves"]) == 10 for g in g1.values())        # turn > max_turns ends the game
     assert s1[0] == 7 and s1[1] + s1[2] == 7 and s1[3] == 70
