@@ -130,6 +130,13 @@ int bk_eval_device(bk_engine *e, const void *d_feats, int feats_dtype, int B, in
  * negative bk_status.  Host buffers must stay alive until bk_wait(ticket) returns.  At most
  * BK_MAX_INFLIGHT tickets may be outstanding; with two or three in flight the H2D copy of one, the
  * kernel of another and the D2H copy of a third run concurrently.
+ * How a request travels (results never depend on it; every variant is bit-identical):
+ *   - at most 256 positions, fp32 engine: no copies at all -- the feature encoder (bk_submit_positions) reads the records from
+ *     the pinned slot, the leaf kernel writes its flag word and outputs into the pinned output block (BK_NO_DIRECT=1: copies);
+ *     up to 128 network tasks run as the cooperative launch (2..12 CUs per board);
+ *   - larger requests: H2D, kernels and D2H on three event-chained streams; host planes of >= 4 MiB are staged by a small
+ *     pool of copy threads whose slices are sent as they land, and from 16 MiB the first 768 positions are launched as soon as
+ *     THEIR planes have arrived, running while the rest is copied (BK_NO_HEAD_PART=1, BK_COPY_THREADS=0: off).
  */
 #define BK_MAX_INFLIGHT 4
 int64_t bk_submit(bk_engine *e, const void *feats, int feats_dtype, int B, int want, float *logits, float *probs,
