@@ -508,6 +508,30 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("GRBM_GUI_ACTIVE",),
               ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVES"))
 
 
+def fold_counter_rows(rows, tot):
+    """One rocprofv3 --pmc pass (rows of *_counter_collection.csv, already filtered to the leaf kernel) -> per-STEP counter
+    values added into `tot`: a step is every launch the timed call makes (3-board rounds + 2-board tail = two kernels, or two
+    grids of one); launches that do not occur in every step are left out.  Per launch kind the mean over its dispatches, summed
+    over the kinds; "_ns" accumulates the kernels' durations alongside GRBM_GUI_ACTIVE (for the clock).  False: nothing usable."""
+    kinds = {}
+    for x in rows:
+        kinds.setdefault((x["Kernel_Name"], x["Grid_Size"]), []).append(x)
+    n = max((len(v) for v in kinds.values()), default=0)
+    if n == 0:
+        return False
+    for v in kinds.values():
+        if len(v) < n:                               # a launch that is not part of every step
+            continue
+        per = {}
+        for x in v:
+            per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
+        for c, vals in per.items():
+            tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
+            if c == "GRBM_GUI_ACTIVE":
+                tot["_ns"] = tot.get("_ns", 0.0) + sum(b for _, b in vals) / len(vals)
+    return True
+
+
 def live_counters(batch, precision, timeout_s=150):
     """The hardware counters of the timed launch, measured in THIS run: one rocprofv3 --pmc pass per counter group (separate
     passes, as MI355X_MICROARCH.md's HBM section prescribes) around a child process -- `python3 bench.py --pmc-child`, started
@@ -534,22 +558,8 @@ def live_counters(batch, precision, timeout_s=150):
             if r.returncode != 0 or not files:
                 return None
             rows = [x for f in files for x in csv.DictReader(open(f)) if kern in x["Kernel_Name"]]
-            steps = {}                                   # dispatches of one step share nothing but order: group by grid size
-            for x in rows:
-                steps.setdefault((x["Kernel_Name"], x["Grid_Size"]), []).append(x)
-            n = max((len(v) for v in steps.values()), default=0)
-            if n == 0:
+            if not fold_counter_rows(rows, tot):
                 return None
-            for (name, grid), v in steps.items():
-                if len(v) < n:                           # a launch that is not part of every step
-                    continue
-                per = {}
-                for x in v:
-                    per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
-                for c, vals in per.items():
-                    tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
-                    if c == "GRBM_GUI_ACTIVE":
-                        tot["_ns"] = tot.get("_ns", 0.0) + sum(b for _, b in vals) / len(vals)
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
             return None
         finally:

@@ -99,3 +99,23 @@ def test_launcher_returns_nonzero_and_ends_the_others_when_a_rank_fails():
     out = _run_bench(["--gpus", "2"], env={"BK_BENCH_LAUNCH_SELFTEST": "fail:1", "BK_BENCH_LAUNCH_TIMEOUT": "60"})
     assert out.returncode == 1 and "rank 1 exited with 3" in out.stderr
     assert not [ln for ln in out.stdout.splitlines() if ln.strip()] and time.time() - t0 < 60
+
+
+def test_counter_rows_fold_into_per_step_values():
+    """bench.py's live PMC passes: rows of rocprofv3's counter_collection.csv -> per-step values.  A step of the timed call
+    is two launches (3-board rounds + 2-board tail); a launch of another size (not in every step) is left out."""
+    def rows(name, grid, n, ctr, value, ns):
+        return [{"Kernel_Name": name, "Grid_Size": str(grid), "Counter_Name": ctr, "Counter_Value": str(value + i % 2),
+                 "Start_Timestamp": "1000", "End_Timestamp": str(1000 + ns)} for i in range(n)]
+    head, tail = "bk_leaf_eval_kernel<3, false>", "bk_leaf_eval_kernel<2, false>"
+    tot = {}
+    assert bench.fold_counter_rows(rows(head, 1310720, 8, "FETCH_SIZE", 49000, 7_500_000) + rows(tail, 131072, 8, "FETCH_SIZE", 37000, 530_000)
+                                   + rows(head, 91648, 1, "FETCH_SIZE", 9999, 800_000), tot)
+    assert tot == {"FETCH_SIZE": 49000.5 + 37000.5}
+    assert bench.fold_counter_rows(rows(head, 1310720, 8, "GRBM_GUI_ACTIVE", 1.43e8, 7_500_000) + rows(tail, 131072, 8, "GRBM_GUI_ACTIVE", 1.0e7, 530_000), tot)
+    assert tot["_ns"] == 8_030_000 and abs(tot["GRBM_GUI_ACTIVE"] - (1.43e8 + 1.0e7 + 1)) < 1e-3
+    three = [r for c, v in (("SQ_WAVES", 20480), ("SQ_INSTS_VALU_MFMA_MOPS_F32", 2.1768e9), ("SQ_VALU_MFMA_BUSY_CYCLES", 1.74e10))
+             for r in rows(head, 1310720, 4, c, v, 7_500_000)]
+    assert bench.fold_counter_rows(three, tot) and abs(tot["SQ_WAVES"] - 20480.5) < 1e-9 and "SQ_VALU_MFMA_BUSY_CYCLES" in tot
+    assert not bench.fold_counter_rows([], {})
+    assert bench.under_profiler() is False and bench.live_counters(4096, "f32") is None      # no GPU here: the passes fail, the caller falls back
