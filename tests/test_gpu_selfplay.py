@@ -64,6 +64,21 @@ def test_config4_full_size_is_independent_of_sharding(engine, generation):
     assert all(named[k] == total[k] for k in selfplay.STATS_FIELDS)
 
 
+def test_config4_does_not_depend_on_what_is_evaluated_when(engine, generation):
+    """Round 3: an expansion evaluates its 4 best-prior children (bk_search_params.eager_top), the rest when the search gets
+    there, and fp32 batches stop at whole rounds of workgroups (bk_pool_set_task_cap) -- the defaults the `generation` fixture
+    ran with.  The same 512 x 400 generation with EVERY child evaluated at its parent's expansion and no cap (rounds 1-2), and
+    with other settings in between, plays the same games move for move with the same root visit counts; only the number of
+    evaluations differs (3.4 M -> 0.7 M)."""
+    local, total = generation
+    for kw in (dict(eager_top=0, task_cap=0), dict(eager_top=8, task_cap=0, n_pools=3), dict(eager_top=2, task_cap=500)):
+        loc, tot = selfplay.self_play(selfplay.EngineEvaluator(engine), record_visits=1, **CFG4, **kw)
+        assert loc["games"] == local["games"] and loc["visits"] == local["visits"], kw
+        assert all(tot[k] == total[k] for k in ("games", "black_wins", "white_wins", "plies", "sum_score", "first_move_hist")), kw
+        if kw["eager_top"] == 0:
+            assert tot["value_evals"] > 4 * total["value_evals"]
+
+
 def test_config4_games_start_like_the_cpu_oracle_run(generation, sds):
     """(iii) anchored to the oracle, not to the HIP path itself: the native pool driven by the CPU oracle nets
     (CallableEvaluator) plays the first plies of sampled games of the SAME generation (same seeds, 400 rollouts,
