@@ -663,7 +663,16 @@ def main():
 
     if args.plan or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
         sys.exit(launch(args, sys.argv[1:]))
-    if "BK_BENCH_CPUS" in os.environ:          # a child of launch(): pin before torch starts its thread pools
+    if "BK_BENCH_CPUS" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("BK_BENCH_NO_PIN"):
+        # a rank started by torch.distributed.run: every rank derives the same plan from sysfs and takes its own slice
+        try:
+            dev = int(os.environ["BK_BENCH_DEVICE"]) if "BK_BENCH_DEVICE" in os.environ else None
+            mine = launch_plan(int(os.environ["WORLD_SIZE"]), device=dev)["ranks"][int(os.environ.get("LOCAL_RANK", "0"))]
+            os.environ["BK_BENCH_CPUS"], os.environ["BK_BENCH_HOST_THREADS"] = mine["cpus"], str(mine["host_threads"])
+            os.environ["BK_BENCH_PINNED_BY"] = "rank"
+        except (IndexError, ValueError, OSError):
+            pass
+    if "BK_BENCH_CPUS" in os.environ:          # pin before torch starts its thread pools
         try:
             os.sched_setaffinity(0, parse_cpulist(os.environ["BK_BENCH_CPUS"]))
         except OSError as e:
@@ -867,8 +876,9 @@ def main():
             "collective_ranks_seen": dist.get_world_size() if dist is not None else 1,
             "collective_backend": (backend if dist is not None else None),
             "per_rank_leaf_evals_per_s": per_rank,
-            "launched_by": ("bench.py launcher" if "BK_BENCH_CPUS" in os.environ else
-                            "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+            "launched_by": ("torch.distributed.run" if os.environ.get("BK_BENCH_PINNED_BY") == "rank" or
+                            ("TORCHELASTIC_RUN_ID" in os.environ and "BK_BENCH_CPUS" not in os.environ) else
+                            "bench.py launcher" if "BK_BENCH_CPUS" in os.environ else "direct"),
             "rank0_cpus": format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,

@@ -119,3 +119,27 @@ def test_counter_rows_fold_into_per_step_values():
     assert bench.fold_counter_rows(three, tot) and abs(tot["SQ_WAVES"] - 20480.5) < 1e-9 and "SQ_VALU_MFMA_BUSY_CYCLES" in tot
     assert not bench.fold_counter_rows([], {})
     assert bench.under_profiler() is False and bench.live_counters(4096, "f32") is None      # no GPU here: the passes fail, the caller falls back
+
+
+def test_ranks_started_by_torchrun_pin_themselves_to_their_slice_of_the_plan():
+    """Under torch.distributed.run nobody hands a rank its CPUs: every rank derives the same plan from sysfs and takes its own
+    slice (ranks were not pinned).  Through the selftest hook: two ranks with torchrun's environment."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BK_BENCH_LAUNCH_SELFTEST="1", TORCHELASTIC_RUN_ID="none")
+        env.pop("BK_BENCH_CPUS", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, cwd=REPO,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[1][1][-500:]
+    d = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    cpus = [set(bench.parse_cpulist(c)) for c in d["rank_cpus"]]
+    allowed = set(os.sched_getaffinity(0))
+    if len(allowed) >= 2:
+        assert not (cpus[0] & cpus[1]) and cpus[0] | cpus[1] == allowed and d["collective_ranks_seen"] == 2
