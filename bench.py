@@ -9,8 +9,8 @@ Launching.  `python3 bench.py --gpus N` starts its own N ranks: the parent makes
 127.0.0.1, splits the host's CPUs between the ranks by the NUMA node of each rank's GPU, starts N fresh children
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the way the reference's
 bin/selfplay.py:177-199 spawns one worker per core), relays rank 0's single JSON line and returns non-zero if any child
-fails.  Under torch.distributed.run (WORLD_SIZE already set) the process is a rank, as before.  `--plan` prints the launch
-plan and exits without touching a GPU.  BK_BENCH_BACKEND=gloo BK_BENCH_DEVICE=0 rehearses the N-rank path on one card.
+fails.  Under torch.distributed.run (WORLD_SIZE already set) the process is a rank; it derives the same plan and pins itself
+to its slice (BK_BENCH_NO_PIN=1: off).  `--plan` prints the launch plan and exits without touching a GPU.  BK_BENCH_BACKEND=gloo BK_BENCH_DEVICE=0 rehearses the N-rank path on one card.
 
 The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the reference's arithmetic width
 (torch fp32, bokego/nnet.py:31-57,73-113) -- timed over exactly --steps launches between barriers.  Beside it:
