@@ -76,7 +76,9 @@ def test_plan_flag_prints_the_plan_and_starts_nothing():
     assert plan["world"] == 4 and len(plan["ranks"]) == 4 and plan["master_addr"] == "127.0.0.1" and plan["master_port"] > 0
     assert plan["argv"] == ["--gpus", "4", "--steps", "3"] and plan["backend"] == "nccl"
     every = [c for r in plan["ranks"] for c in bench.parse_cpulist(r["cpus"])]
-    assert sorted(every) == sorted(os.sched_getaffinity(0))
+    assert len(every) == len(set(every)) and set(every) <= set(os.sched_getaffinity(0))      # nothing shared, nothing foreign
+    if not plan["gpu_numa_nodes"]:           # no GPU topology in sysfs (the build container): everything allowed is dealt out;
+        assert sorted(every) == sorted(os.sched_getaffinity(0))   # with one, only the CPUs of the GPUs' NUMA nodes are
 
 
 def test_launcher_starts_n_ranks_and_relays_one_line():
@@ -90,7 +92,7 @@ def test_launcher_starts_n_ranks_and_relays_one_line():
     assert d["n_gpus"] == 3 and d["collective_ranks_seen"] == 3 and d["sum_of_ranks_plus_1"] == 6.0 and d["steps"] == 7
     cpus = [set(bench.parse_cpulist(c)) for c in d["rank_cpus"]]
     if len(os.sched_getaffinity(0)) >= 3:
-        assert not (cpus[0] & cpus[1]) and not (cpus[1] & cpus[2]) and set().union(*cpus) == set(os.sched_getaffinity(0))
+        assert not (cpus[0] & cpus[1]) and not (cpus[1] & cpus[2]) and set().union(*cpus) <= set(os.sched_getaffinity(0))
 
 
 def test_launcher_returns_nonzero_and_ends_the_others_when_a_rank_fails():
@@ -118,7 +120,10 @@ def test_counter_rows_fold_into_per_step_values():
              for r in rows(head, 1310720, 4, c, v, 7_500_000)]
     assert bench.fold_counter_rows(three, tot) and abs(tot["SQ_WAVES"] - 20480.5) < 1e-9 and "SQ_VALU_MFMA_BUSY_CYCLES" in tot
     assert not bench.fold_counter_rows([], {})
-    assert bench.under_profiler() is False and bench.live_counters(4096, "f32") is None      # no GPU here: the passes fail, the caller falls back
+    assert bench.under_profiler() is False
+    from bokego_amd import _lib
+    if _lib.load().bk_device_count() == 0:
+        assert bench.live_counters(4096, "f32") is None      # no GPU here: the passes fail, the caller falls back
 
 
 def test_ranks_started_by_torchrun_pin_themselves_to_their_slice_of_the_plan():
@@ -142,4 +147,4 @@ def test_ranks_started_by_torchrun_pin_themselves_to_their_slice_of_the_plan():
     cpus = [set(bench.parse_cpulist(c)) for c in d["rank_cpus"]]
     allowed = set(os.sched_getaffinity(0))
     if len(allowed) >= 2:
-        assert not (cpus[0] & cpus[1]) and cpus[0] | cpus[1] == allowed and d["collective_ranks_seen"] == 2
+        assert not (cpus[0] & cpus[1]) and cpus[0] | cpus[1] <= allowed and d["collective_ranks_seen"] == 2
