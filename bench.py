@@ -320,6 +320,10 @@ def launch_plan(n, allowed=None, gpu_nodes=None, node_cpus=None, quota=None, dev
     devs = [device if device is not None else r for r in range(n)]
     node_of = [gpu_nodes[d] if d < len(gpu_nodes) else -1 for d in devs]
     local = {nd: [c for c in node_cpus.get(nd, []) if c in set(allowed)] for nd in set(node_of)}
+    # NUMA-local slices only when EVERY rank's GPU has a known node with enough CPUs for its ranks: a mixture of local and
+    # flat slices would hand the same CPUs out twice
+    if any(nd < 0 or len(local.get(nd) or []) < node_of.count(nd) for nd in node_of):
+        node_of = [-1] * n
     ranks = []
     for r in range(n):
         nd = node_of[r]

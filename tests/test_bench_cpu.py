@@ -62,6 +62,11 @@ def test_launch_plan_splits_whole_cores_by_numa_node():
     # topology not visible (this container): an even split of what the process may run on, nothing lost, nothing shared
     flat = bench.launch_plan(3, allowed=range(8), gpu_nodes=[], node_cpus={}, quota=None, core_of={})
     assert [r["cpus"] for r in flat["ranks"]] == ["0-1", "2-4", "5-7"]
+    # a box that shows only SOME of the GPUs' topology (the one-GPU lease: node 0 of device 0 only) gets the flat split for every
+    # rank -- never a NUMA slice for one rank and a flat one overlapping it for the others
+    mixed = bench.launch_plan(4, allowed=range(256), gpu_nodes=[0], node_cpus=node_cpus, quota=16, core_of={c: c % 128 for c in range(256)})
+    got = [c for r in mixed["ranks"] for c in bench.parse_cpulist(r["cpus"])]
+    assert len(got) == len(set(got)) == 256 and all(r["numa_node"] == -1 for r in mixed["ranks"])
     # one-GPU rehearsal: every rank opens the same device; the quota bounds the threads
     reh = bench.launch_plan(2, allowed=range(256), gpu_nodes=[1], node_cpus=node_cpus, quota=16, device=0,
                             core_of={c: c % 128 for c in range(256)})
