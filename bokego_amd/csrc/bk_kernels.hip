@@ -88,7 +88,13 @@ struct Geo {
     static_assert(L0_BYTES <= L3_BYTES, "the layer-0 input lives inside the activation region");
         // 8 waves per workgroup = two per SIMD: while one wave issues its loads and waits, the other's MFMA keeps the matrix
     // pipe busy (measured on the earlier 32-row-tile loop: 65.06 cycles per 64-cycle MFMA with one wave per SIMD, +1.1 % with two)
+#if BK_EXP & 4
+    // timing experiment (make exp EXP=4, wrong results): a THIRD wave per SIMD that works on the packed-FP32 vector ALU beside the
+    // two MFMA waves; 3-board workgroups only
+    static constexpr int NW = NB == 3 ? 12 : 8;
+#else
     static constexpr int NW = 8;
+#endif
     static constexpr int THREADS = 64 * NW;
     static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one shared record: never read)
     static constexpr int HS_FLOATS = NB * 96;
@@ -140,7 +146,11 @@ struct Tiles {
     // (1 board: 81 points in 6 tiles, too few per edge class to fill a tile: every tile runs every tap)
     static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 6;
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
+#if BK_EXP & 4
+    static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 7 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;   // tile 7: the vector waves' share
+#else
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
+#endif
     static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
 };
 struct TileRow { int b, y, x; bool valid; };
@@ -344,6 +354,52 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     }
 }
 
+#if BK_EXP & 4
+// timing experiment: what a vector wave would issue for its share of a 3x3 layer -- 6 of the 22 positions of the two dropped y-edge
+// tiles, all 128 output channels (a lane = two of them), 6 of 9 taps: per tap and channel group 8 weight loads of 16 B (the group's
+// 8 KiB), per position 4 LDS reads of 16 B (one address for the whole wave) and 16 v_pk_fma_f32.  The operand pairing is arbitrary:
+// only the instruction mix and the traffic are those of a real implementation.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void valu_group(const char* ap, const f32x4 (&W)[8], f32x2 (&acc)[6]) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        f32x4 X[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[q] = *reinterpret_cast<const f32x4*>(ap + p * REC3 + q * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 w = W[2 * q + (j >> 1)];
+                acc[p] = __builtin_elementwise_fma(j & 1 ? f32x2{w[2], w[3]} : f32x2{w[0], w[1]}, f32x2{X[q][j], X[q][j]}, acc[p]);
+            }
+    }
+}
+__device__ __forceinline__ void valu_layer(const char* actb, const float* __restrict__ wl, int lane, int vw, f32x2 (&acc)[6]) {
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl), 0, 0x7ffffff0, 0x00020000);
+    // a lane's 16 B of load i: (cout a, cout b) x two input channels -- operand pairs as they are loaded, the activation
+    // broadcast by op_sel: no moves beside the FMAs.  Two weight buffers: the next group is fetched while this one is consumed.
+    f32x4 Wa[8], Wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Wa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, 0, 0));
+    int boff = 8192;
+#pragma unroll 1
+    for (int t = 0; t < 6; ++t) {
+        const char* ap = actb + __builtin_amdgcn_readfirstlane((1 + 3 * vw) * RP3 + (1 + t) * REC3);
+#pragma unroll 1
+        for (int g = 0; g < 8; g += 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Wb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, boff, 0));
+            valu_group(ap + g * 64, Wa, acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Wa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, boff + 8192, 0));
+            valu_group(ap + g * 64 + 64, Wb, acc);
+            boff = boff + 16384 < 47 * 8192 ? boff + 16384 : 0;
+        }
+    }
+}
+#endif
+
 // bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 16*(CTW*wn + ct) + 4*kq .. +3 of its position
 template <class F>
 __device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[F::RT][F::CTW],
@@ -525,6 +581,36 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     }
     stage_input<NB, G::THREADS>(a, actb, b0, nb, tid);
     __syncthreads();
+#if BK_EXP & 4
+    if (NB == 3 && wave >= 8) {
+        // timing experiment: the vector waves' whole life -- the workgroup's barriers in the same order, and in every 3x3 layer
+        // the instruction mix of their share (valu_layer).  A separate path so that no register of the MFMA path stays live here.
+        __syncthreads();                               // layer 0: after the conv
+        for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {
+            const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
+            const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
+            *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                               // halo cleared
+        __syncthreads();                               // layer 0 stored
+#pragma unroll 1
+        for (int L = 1; L < 7; ++L) {
+            f32x2 va[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) va[p] = f32x2{0.f, 0.f};
+#if !(BK_EXP & 8)                                     // EXP=12: idle vector waves -- what the 168-register cap alone costs the MFMA waves
+            valu_layer(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, lane, wave - 8, va);
+#endif
+            __syncthreads();
+            float sink = 0.f;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) sink += va[p][0] + va[p][1];
+            if (sink == 12345.678f) reinterpret_cast<float*>(smem + dummy_byte)[lane] = sink;   // keeps the FMAs alive
+            __syncthreads();
+        }
+        return;
+    }
+#endif
 
     STAMP(1);
     constexpr int RT = F::RT;
@@ -822,7 +908,9 @@ constexpr long tile_taps(int kw) {
     const int ny = (F::Y0a >= 0 ? F::Y0b - F::Y0a : 0) + (F::Y1 >= 0);
     return (long)(F::A1 - F::A0) * taps + (long)(nx + ny) * (taps - skip);
 }
+#if !(BK_EXP & 4)
 static_assert(tile_taps<Tiles<3>>(3) == 63 && tile_taps<Tiles<3>>(5) == 170, "3 boards: 63 of 72 / 170 of 200 tile-taps");
+#endif
 static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 54, "2 boards: 87 of 99; 1 board: all 54");
 // FLOP the matrix unit executes for ONE net on one NB-board workgroup: per (tile, tap) 7 k-steps in layer 0 (28 input
 // slots) resp. 32 in a 3x3 layer, x 8 cout tiles, of v_mfma_f32_16x16x4_f32 (2 * 16 * 16 * 4 = 2,048 FLOP each)
