@@ -47,6 +47,7 @@ sys.path.insert(0, REPO)
 FLOP_PER_LEAF = 266_838_272          # SURVEY 8d / BASELINE.md 3: valid taps, both nets
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md chip table (dense, fp32 in / fp32 acc)
 PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md chip table (dense f16/bf16 MFMA)
+PEAK_HBM_GBPS = 8000.0               # MI355X_MICROARCH.md chip table (HBM3E)
 BYTES_PER_LEAF = 8748 + 328          # compulsory HBM bytes (f32 planes in, 81 probs + value out)
 BATCH = 4096
 TOL = {"logit": 1e-4, "prob": 1e-5, "value": 1e-4}   # BASELINE.json north_star / SURVEY 8d config 1
@@ -619,6 +620,10 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
          "algorithmic_flop_per_launch": batch * FLOP_PER_LEAF, "algorithmic_hbm_bytes_per_launch": batch * BYTES_PER_LEAF,
          "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"), "pmc_source": pmc.get("source"),
          "pmc_file_fallback": None if live else file_source}
+    # the other roof, as BASELINE.json's north_star words it (HBM GB/s against the chip's peak): three orders of magnitude away
+    r["hbm"] = {"peak_GBps": PEAK_HBM_GBPS, "algorithmic_GBps": batch * BYTES_PER_LEAF / (kern_ms * 1e-3) / 1e9,
+                "measured_GBps": r["traffic"] / (kern_ms * 1e-3) / 1e9 if r["traffic"] else None}
+    r["hbm"]["frac_measured"] = r["hbm"]["measured_GBps"] / PEAK_HBM_GBPS if r["hbm"]["measured_GBps"] else None
     if live and live.get("executed_mfma_flop_per_launch"):
         r["pmc_executed_mfma_flop_per_launch"] = live["executed_mfma_flop_per_launch"]
     if f16:

@@ -45,6 +45,9 @@ def test_bench_line_contract():
         assert abs(r["pmc_executed_mfma_flop_per_launch"] / r["executed_mfma_flop_per_launch"] - 1) < 0.01     # counters = tile tables
     else:       # no rocprofv3 on this box (or a pass failed): the line says where its counters come from instead
         assert r["pmc_source"].startswith("from_file:") and r["pmc_file_fallback"] == r["pmc_source"]
+    h = r["hbm"]                                            # north_star's wording: HBM GB/s against the chip's peak
+    assert h["peak_GBps"] == 8000.0 and abs(h["algorithmic_GBps"] - r["algorithmic_hbm_bytes_per_launch"] / r["kernel_ms"] / 1e6) < 1e-6
+    assert h["measured_GBps"] is None or (h["algorithmic_GBps"] < h["measured_GBps"] < 100 and h["frac_measured"] < 0.02)
     par = d["config"]["parity"]
     assert par["max_abs_dlogit"] < 1e-4 and par["max_abs_dprob"] < 1e-5 and par["max_abs_dvalue"] < 1e-4
     f16 = d["f16x2"]
