@@ -348,25 +348,35 @@ def load_state_dict(path):
     return ck["model_state_dict"] if "model_state_dict" in ck else ck
 
 
-def main(argv=None):
+def build_parser():
+    """The reference launcher's flags (boke.py:15-26: -t -r -p -v -g/--gpu --simulate) with the same meaning, plus this
+    engine's own.  `-g` may be given bare, as the reference's store_true flag is, or with a GPU index."""
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     ap = argparse.ArgumentParser(description="BokeGo GTP engine on the MI355X leaf-evaluation engine")
     ap.add_argument("-t", metavar="SEC", type=float, default=10.0, help="time limit in seconds for each move")
     ap.add_argument("-r", type=int, default=None, help="number of rollouts per move (overrides -t)")
     ap.add_argument("-p", metavar="PATH", default=os.path.join(golden, "policy_19.bkw"), help="policy weights (.pt/.bkw)")
     ap.add_argument("-v", metavar="PATH", default=os.path.join(golden, "value_synth.bkw"), help="value weights (.pt/.bkw)")
-    ap.add_argument("-g", "--gpu", type=int, default=0, help="GPU index")
+    ap.add_argument("-g", "--gpu", type=int, nargs="?", const=0, default=0, metavar="INDEX",
+                    help="GPU index (default 0; the networks always run on the GPU -- a bare -g is accepted as in the reference)")
+    ap.add_argument("--simulate", action="store_true",
+                    help="enable simulations to end of game (slow; the reference's flag: searches with the Python tree)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     ap.add_argument("--ponder", action="store_true")
     ap.add_argument("--python-tree", action="store_true", help="search with the Python tree instead of the native one")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
 
     from . import nnet
     pi = nnet.HipPolicyNet(load_state_dict(args.p), device_id=args.gpu, precision=args.precision)
     val = nnet.HipValueNet(load_state_dict(args.v), device_id=args.gpu, precision=args.precision)
-    cls, root = (GTP, Go_MCTS()) if args.python_tree else (NativeGTP, Position())
-    gtp = cls(root, pi, val, no_sim=True, time_lim=None if args.r else args.t, n_rollouts=args.r, pondering=args.ponder)
+    python_tree = args.python_tree or args.simulate      # the native tree implements the no-simulation mode only
+    cls, root = (GTP, Go_MCTS()) if python_tree else (NativeGTP, Position())
+    gtp = cls(root, pi, val, no_sim=not args.simulate, time_lim=None if args.r else args.t, n_rollouts=args.r, pondering=args.ponder)
     gtp.start()
 
 

@@ -127,6 +127,8 @@ class Go_MCTS(go.Game):
             if tries >= go.N ** 2:
                 return go.PASS
             d.probs[move] = 0
+            if not float(d.probs.sum()) > 0:       # every move with a non-zero probability is used up: the reference's
+                return go.PASS                     # sample() raises here (multinomial of an all-zero row); pass instead
             move = d.sample().item()
             tries += 1
         return move

@@ -85,3 +85,26 @@ def test_komi_command_stays_in_force(nets, native, tmp_path):
     assert g.send("komi x") == "? invalid komi value\n\n"
     if native:
         g.close()
+
+
+def test_launcher_accepts_the_reference_launchers_command_lines():
+    """boke.py:15-26: -t -r -p -v, a BARE -g/--gpu (store_true there) and --simulate must parse with the reference's meaning."""
+    from bokego_amd.gtp import build_parser
+    ap = build_parser()
+    a = ap.parse_args(["-g", "-r", "1600"])
+    assert a.gpu == 0 and a.r == 1600 and a.simulate is False and a.t == 10.0
+    a = ap.parse_args(["-r", "200", "--gpu", "-p", "p.pt", "-v", "v.pt", "-t", "2.5"])
+    assert a.gpu == 0 and a.p == "p.pt" and a.v == "v.pt" and a.t == 2.5
+    assert ap.parse_args(["-g", "3"]).gpu == 3 and ap.parse_args([]).gpu == 0
+    assert ap.parse_args(["--simulate"]).simulate is True
+
+
+def test_simulation_mode_on_the_python_tree(nets):
+    """--simulate = no_sim False (boke.py:42): rollouts are scored by a playout to the end of the game, the value net is not
+    needed (mcts.py:59-60 only requires it in no-simulation mode)."""
+    torch.manual_seed(0)
+    g = GTP(Go_MCTS(), nets[0], None, no_sim=False, time_lim=None, n_rollouts=6, expand_thresh=2)
+    g.running = True
+    reply = g.send("genmove b")
+    assert reply.startswith("= ") and reply.strip() not in ("=", "= resign")
+    assert g.send("genmove w").startswith("= ")
