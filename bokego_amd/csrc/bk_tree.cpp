@@ -630,16 +630,21 @@ public:
         grow(threads - 1);
         Job job{&fn, n, threads - 1};
         job.id = ++last_id_;
-        cur_.store(&job, std::memory_order_release);
-        announced_.store(job.id, std::memory_order_release);     // what sleepers watch (they must not look into `job`)
-        if (sleepers_.load(std::memory_order_acquire) > 0) {
+        // Publishing and retiring a job are store-then-load hand-shakes with the workers (Dekker-style): the caller stores
+        // cur_ / announced_ and then reads inside_ / sleepers_, a worker raises inside_ / sleepers_ and then reads cur_ /
+        // announced_.  Each side must see the other's store or be seen by it, which only sequentially consistent
+        // operations give (with release/acquire the caller's load may pass its own store: a late worker then walked into
+        // a job whose stack frame was gone -- a rare segfault in whatever the calling thread did next).
+        cur_.store(&job, std::memory_order_seq_cst);
+        announced_.store(job.id, std::memory_order_seq_cst);     // what sleepers watch (they must not look into `job`)
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
             std::lock_guard<std::mutex> g(m_);
             cv_.notify_all();
         }
         work(job);
         while (job.done.load(std::memory_order_acquire) < n) cpu_relax();
-        cur_.store(nullptr, std::memory_order_release);
-        while (inside_.load(std::memory_order_acquire) != 0) cpu_relax();   // nobody still looks at `job`
+        cur_.store(nullptr, std::memory_order_seq_cst);
+        while (inside_.load(std::memory_order_seq_cst) != 0) cpu_relax();   // nobody still looks at `job`
     }
     ~Team() {
         quit_.store(true);
@@ -674,27 +679,27 @@ private:
         auto idle_since = std::chrono::steady_clock::now();
         int spins = 0;
         while (!quit_.load(std::memory_order_relaxed)) {
-            inside_.fetch_add(1, std::memory_order_acq_rel);
-            Job* j = cur_.load(std::memory_order_acquire);
+            inside_.fetch_add(1, std::memory_order_seq_cst);
+            Job* j = cur_.load(std::memory_order_seq_cst);
             if (j && j->id != seen) {
                 seen = j->id;
                 if (j->joined.fetch_add(1, std::memory_order_relaxed) < j->helpers) work(*j);
-                inside_.fetch_sub(1, std::memory_order_acq_rel);
+                inside_.fetch_sub(1, std::memory_order_seq_cst);
                 idle_since = std::chrono::steady_clock::now();
                 spins = 0;
                 continue;
             }
-            inside_.fetch_sub(1, std::memory_order_acq_rel);
+            inside_.fetch_sub(1, std::memory_order_seq_cst);
             cpu_relax();
             if (++spins < 2000) continue;                      // ~a few microseconds between looks at the clock
             spins = 0;
             if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(2)) continue;
             {                                                  // nothing for 2 ms: sleep until the next job is announced
                 std::unique_lock<std::mutex> g(m_);
-                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                sleepers_.fetch_add(1, std::memory_order_seq_cst);
                 cv_.wait_for(g, std::chrono::milliseconds(50),
-                             [&] { return quit_.load() || announced_.load(std::memory_order_acquire) != seen; });
-                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                             [&] { return quit_.load() || announced_.load(std::memory_order_seq_cst) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_seq_cst);
             }
             idle_since = std::chrono::steady_clock::now();
         }
@@ -784,6 +789,38 @@ int bk_pool_collect_pos(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
         bk_pos_liberties(pos, libs);
         out[row] = *pos;
     });
+}
+
+// Stress of the worker team (tests/test_selfplay_cpu.py): `jobs` parallel regions of a few items each, every so often after a
+// pause long enough for the workers to fall asleep, so that workers keep arriving late at regions that are being retired.
+// A region's bookkeeping lives on the caller's stack; after every region the same stack area is filled with a pattern and
+// checked a little later -- a worker that still walked into the retired region would change it.
+// Returns 0 when every item of every region ran exactly once and no pattern was touched.
+namespace {
+__attribute__((noinline)) int team_region(int threads, int n) {
+    std::atomic<int> hits[8];
+    for (auto& h : hits) h.store(0, std::memory_order_relaxed);
+    Team::get().run(threads, n, [&](int i) { hits[i].fetch_add(1, std::memory_order_relaxed); });
+    for (int i = 0; i < n; ++i)
+        if (hits[i].load(std::memory_order_relaxed) != 1) return 1;
+    return 0;
+}
+__attribute__((noinline)) int team_canary(int spins) {
+    volatile unsigned char pad[768];
+    for (auto& b : pad) b = 0xA5;
+    for (int i = 0; i < spins; ++i) __builtin_ia32_pause();
+    for (auto& b : pad)
+        if (b != 0xA5) return 1;
+    return 0;
+}
+}  // namespace
+int bk_team_selftest(int threads, int jobs) {
+    for (int k = 0; k < jobs; ++k) {
+        if (team_region(threads, 1 + k % 7)) return 1 + k;
+        if (team_canary(k % 64)) return -(1 + k);
+        if (k % 4096 == 4095) std::this_thread::sleep_for(std::chrono::milliseconds(3));
+    }
+    return 0;
 }
 
 void bk_pool_phase_seconds(const bk_pool* p, double* out3) {   // advance, emit, deliver

@@ -111,6 +111,8 @@ void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 /* host seconds this pool has spent so far advancing its games (select / expand / backup), writing request rows, and taking
  * deliveries: out3 = {advance, emit, deliver} (tools/selfplay_breakdown.py) */
 void bk_pool_phase_seconds(const bk_pool *p, double *out3);
+/* stress of the worker threads the pools share (`jobs` short parallel regions on `threads` threads); 0 = every item ran once */
+int bk_team_selftest(int threads, int jobs);
 int bk_pool_n_games(const bk_pool *p);
 int bk_pool_n_done(const bk_pool *p);
 int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);

@@ -231,3 +231,12 @@ def test_pt_checkpoint_through_launcher_to_engine(sds, tmp_path):
         assert rep[3] == "= G5"                                  # the reference's reply to E5 at 200 rollouts (gtp_transcript.json)
         assert rep[4].startswith("= W+") or rep[4].startswith("= B+")
         assert rep[5] == "= E5\nG5"
+
+
+def test_worker_team_on_the_gpu_host():
+    """tests/test_selfplay_cpu.py::test_worker_team_survives_late_workers again, on the GPU box's own CPU: the hand-shake
+    bug it guards against (a worker walking into a retired parallel region) showed within a few hundred regions on the
+    EPYC hosts of this pool and never on the build container's Xeon.  Needs no GPU; marked gpu to run where it matters."""
+    lib = selfplay.treelib()
+    for threads in (2, 3, 6, 12):
+        assert lib.bk_team_selftest(threads, 300_000) == 0

@@ -288,3 +288,15 @@ def test_a_task_cap_on_the_batches_only_changes_how_games_are_grouped():
     pool = selfplay.GamePool([1, 2, 3], selfplay.search_params(rollouts=10, max_turns=3), cap=256, threads=1)
     pool.set_task_cap(768)
     pool.close()
+
+
+def test_worker_team_survives_late_workers():
+    """The pools' worker threads (bk_tree.cpp, Team) join short parallel regions and fall asleep in between; a worker that
+    arrives while a region is being retired must never walk into it: the region's bookkeeping is on the caller's stack.
+    With release/acquire hand-shakes it did (the caller's load of `inside_` may pass its own store to `cur_`): 2 of 37
+    self-play processes on the GPU box died inside bk_submit_positions, the next native call on that stack.  The selftest
+    checks a stack pattern after every region; the old ordering trips it within a few hundred regions on the EPYC hosts
+    (tests/test_gpu_selfplay.py runs it there), sequentially consistent hand-shakes pass millions."""
+    lib = selfplay.treelib()
+    for threads in (2, 3, 6):
+        assert lib.bk_team_selftest(threads, 200_000) == 0
