@@ -831,7 +831,7 @@ def main():
         # host cores are shared by the ranks: a launch() child got its slice and thread count from the plan, a
         # torch.distributed.run rank sees every CPU and takes 1/world of them (of the cgroup quota when there is one)
         threads = int(os.environ.get("BK_BENCH_HOST_THREADS", 0)) or max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
-        threads = max(1, min(12, threads, (args.selfplay_games // world) // 32 or 1))    # <= one per 16 games of a pool (two pools)
+        threads = max(1, min(12, threads, (args.selfplay_games // world) // 16 or 1))    # <= one per 8 games of a pool (two pools): selfplay.default_threads
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
               "search": "an expansion evaluates its best-prior children only (bk_search_params.eager_top), the rest when a rollout "

@@ -111,7 +111,9 @@ def default_threads(n_games):
     """Host threads of a pool: the team's workers spin between the steps of a generation (bk_tree.cpp, Team), so they must
     fit the CPUs this process really owns -- the cgroup quota, not the affinity mask -- with room left for the Python thread
     and the HIP runtime's: 12 of a 16-CPU share (16 threads: 25.6 k games/min, erratic, against 27.6 k with 12), and no more
-    than one per 16 games (64 games: 4 threads 18.7 k games/min, 16 threads 13.7 k; profiles/r03_eager_top.txt)."""
+    than one per 8 games of the pool: a rank's share of configs[3] at 8 / 4 / 2 / 1 ranks (two pools of 32 / 64 / 128 / 256
+    games) is fastest with 4 / 4-8 / 8 / 8-12 threads and flat beyond (64 games: 0.283 s with 1 thread, 0.221 with 2, 0.203
+    with 4 to 8; profiles/r03_shard_of_8_sweep.txt)."""
     own = len(os.sched_getaffinity(0))
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -119,7 +121,7 @@ def default_threads(n_games):
             own = min(own, max(1, int(int(q) / int(per))))
     except (OSError, ValueError):
         pass
-    return max(1, min(12, own - 4 if own > 8 else own // 2, max(1, n_games // 16)))
+    return max(1, min(12, own - 4 if own > 8 else own // 2, max(1, n_games // 8)))
 
 
 class GamePool:

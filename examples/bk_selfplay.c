@@ -76,9 +76,9 @@ int main(int argc, char **argv) {
         uint64_t *ps = malloc(sizeof(uint64_t) * (mine / npools + 1));
         int k = 0;
         for (int j = i; j < mine; j += npools) ps[k++] = seeds[j];
-        /* the pools' worker threads spin between steps: 12 of a 16-CPU share, and no more than one per 16 games */
+        /* the pools' worker threads spin between steps: 12 of a 16-CPU share, and no more than one per 8 games */
         int threads = ncpu > 8 ? (ncpu - 4 < 12 ? (int)ncpu - 4 : 12) : (int)ncpu / 2;
-        if (threads > k / 16) threads = k / 16;
+        if (threads > k / 8) threads = k / 8;
         s[i].pool = bk_pool_create(k, &prm, ps, threads < 1 ? 1 : threads);
         /* fp32 engine: a launch costs whole rounds of 3-board workgroups (256 CUs x 3 tasks); hold the batches to the whole
          * number of rounds nearest to what the pool asks for (~3 tasks per game and step), minus the per-net rounding */
