@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 4
+BK_ABI_VERSION = 5
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -57,6 +57,7 @@ SYMBOLS = {
     "bk_engine_create": (ctypes.c_int, [ctypes.POINTER(PolicyWeights), ctypes.POINTER(ValueWeights), ctypes.c_int,
                                         ctypes.c_int, ctypes.POINTER(_P)]),
     "bk_engine_destroy": (ctypes.c_int, [_P]),
+    "bk_engine_set_weights": (ctypes.c_int, [_P, _P, _P]),
     "bk_eval": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "bk_eval_u8": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "bk_eval_device": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),

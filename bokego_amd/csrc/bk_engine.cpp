@@ -316,11 +316,15 @@ void pack_trunk16(const bk_trunk_weights& t, std::vector<_Float16>& wfrag, std::
     }
 }
 
+// *out == nullptr: allocate and fill; otherwise refill the buffer that is there (bk_engine_set_weights: every weight array
+// has a size fixed by the architecture)
 template <typename T>
 int upload(bk_engine* e, const std::vector<T>& h, const T** out) {
-    void* d = nullptr;
-    HIP_TRY(e, hipMalloc(&d, h.size() * sizeof(T)));
-    e->dev_allocs.push_back(d);
+    void* d = const_cast<T*>(*out);
+    if (!d) {
+        HIP_TRY(e, hipMalloc(&d, h.size() * sizeof(T)));
+        e->dev_allocs.push_back(d);
+    }
     HIP_TRY(e, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(d);
     return BK_OK;
@@ -344,6 +348,45 @@ int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, doub
     np.inv_sa16 = 1.f / kSa16;
     if ((rc = upload(e, w16, &np.wfrag16))) return rc;
     if ((rc = upload(e, b16, &np.bias16))) return rc;
+    return BK_OK;
+}
+
+bool weights_ok(const bk_policy_weights* policy, const bk_value_weights* value) {
+    if (policy && !trunk_ok(policy->trunk)) return false;
+    if (value) {
+        const bk_value_head_weights& h = value->head;
+        if (!trunk_ok(value->trunk) || !h.bn_w || !h.bn_b || !h.bn_mean || !h.bn_var || !h.lin1_w || !h.lin1_b ||
+            !h.lin_bn_w || !h.lin_bn_b || !h.lin_bn_mean || !h.lin_bn_var || !h.lin2_w || !h.lin2_b)
+            return false;
+    }
+    return true;
+}
+
+// fold BatchNorm, pack and upload the weights of the nets given (nullptr: that net is left alone); device buffers are
+// allocated on first use and refilled afterwards
+int load_weights(bk_engine* e, const bk_policy_weights* policy, const bk_value_weights* value) {
+    int rc;
+    if (policy) {
+        if ((rc = setup_trunk(e, policy->trunk, e->net[0], 1.0, 0.0))) return rc;
+    }
+    if (value) {
+        const bk_value_head_weights& h = value->head;
+        const double s = (double)h.bn_w[0] / std::sqrt((double)h.bn_var[0] + kBnEps);
+        const double shift = (double)h.bn_b[0] - (double)h.bn_mean[0] * s;
+        if ((rc = setup_trunk(e, value->trunk, e->net[1], s, shift))) return rc;
+        // lin1 (64,81) + BatchNorm1d(64) folded, stored transposed [81][64] for coalesced reads
+        std::vector<float> w1t(81 * 64), b1(64), w2(64);
+        for (int j = 0; j < 64; ++j) {
+            const double sj = (double)h.lin_bn_w[j] / std::sqrt((double)h.lin_bn_var[j] + kBnEps);
+            for (int q = 0; q < 81; ++q) w1t[q * 64 + j] = (float)((double)h.lin1_w[j * 81 + q] * sj);
+            b1[j] = (float)(((double)h.lin1_b[j] - (double)h.lin_bn_mean[j]) * sj + (double)h.lin_bn_b[j]);
+            w2[j] = h.lin2_w[j];
+        }
+        if ((rc = upload(e, w1t, &e->net[1].lin1_wt))) return rc;
+        if ((rc = upload(e, b1, &e->net[1].lin1_b))) return rc;
+        if ((rc = upload(e, w2, &e->net[1].lin2_w))) return rc;
+        e->net[1].lin2_b = h.lin2_b[0];
+    }
     return BK_OK;
 }
 
@@ -566,13 +609,8 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     *out = nullptr;
     if (!policy && !value) return fail(nullptr, BK_ERR_ARG, "at least one of policy/value weights is required");
     if (max_batch <= 0) return fail(nullptr, BK_ERR_ARG, "max_batch must be positive");
-    if (policy && !trunk_ok(policy->trunk)) return fail(nullptr, BK_ERR_ARG, "policy weights: NULL tensor pointer");
-    if (value) {
-        const bk_value_head_weights& h = value->head;
-        if (!trunk_ok(value->trunk) || !h.bn_w || !h.bn_b || !h.bn_mean || !h.bn_var || !h.lin1_w || !h.lin1_b ||
-            !h.lin_bn_w || !h.lin_bn_b || !h.lin_bn_mean || !h.lin_bn_var || !h.lin2_w || !h.lin2_b)
-            return fail(nullptr, BK_ERR_ARG, "value weights: NULL tensor pointer");
-    }
+    if (!weights_ok(policy, nullptr)) return fail(nullptr, BK_ERR_ARG, "policy weights: NULL tensor pointer");
+    if (!weights_ok(nullptr, value)) return fail(nullptr, BK_ERR_ARG, "value weights: NULL tensor pointer");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, BK_ERR_NO_GPU, "no HIP device visible (the engine has no CPU fallback)");
@@ -612,27 +650,7 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
     TRY_CREATE(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
 
-    if (policy) {
-        if ((rc = setup_trunk(e, policy->trunk, e->net[0], 1.0, 0.0))) return bail(rc);
-    }
-    if (value) {
-        const bk_value_head_weights& h = value->head;
-        const double s = (double)h.bn_w[0] / std::sqrt((double)h.bn_var[0] + kBnEps);
-        const double shift = (double)h.bn_b[0] - (double)h.bn_mean[0] * s;
-        if ((rc = setup_trunk(e, value->trunk, e->net[1], s, shift))) return bail(rc);
-        // lin1 (64,81) + BatchNorm1d(64) folded, stored transposed [81][64] for coalesced reads
-        std::vector<float> w1t(81 * 64), b1(64), w2(64);
-        for (int j = 0; j < 64; ++j) {
-            const double sj = (double)h.lin_bn_w[j] / std::sqrt((double)h.lin_bn_var[j] + kBnEps);
-            for (int q = 0; q < 81; ++q) w1t[q * 64 + j] = (float)((double)h.lin1_w[j * 81 + q] * sj);
-            b1[j] = (float)(((double)h.lin1_b[j] - (double)h.lin_bn_mean[j]) * sj + (double)h.lin_bn_b[j]);
-            w2[j] = h.lin2_w[j];
-        }
-        if ((rc = upload(e, w1t, &e->net[1].lin1_wt))) return bail(rc);
-        if ((rc = upload(e, b1, &e->net[1].lin1_b))) return bail(rc);
-        if ((rc = upload(e, w2, &e->net[1].lin2_w))) return bail(rc);
-        e->net[1].lin2_b = h.lin2_b[0];
-    }
+    if ((rc = load_weights(e, policy, value))) return bail(rc);
 #ifdef BK_STAMPS
     TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
     e->dev_allocs.push_back(e->d_stamps);
@@ -676,6 +694,19 @@ int bk_engine_destroy(bk_engine* e) {
     delete e->copy_pool;
     delete e;
     return BK_OK;
+}
+
+int bk_engine_set_weights(bk_engine* e, const bk_policy_weights* policy, const bk_value_weights* value) {
+    if (!e) return BK_ERR_ARG;
+    if (!policy && !value) return fail(e, BK_ERR_ARG, "neither policy nor value weights given");
+    if ((policy && !e->has_policy) || (value && !e->has_value))
+        return fail(e, BK_ERR_ARG, "the engine was created without that net");
+    if (!weights_ok(policy, value)) return fail(e, BK_ERR_ARG, "weights: NULL tensor pointer");
+    for (auto& s : e->slots)
+        if (s.busy) return fail(e, BK_ERR_ARG, "tickets outstanding: bk_wait for them before replacing the weights");
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (hipStream_t st : {e->s_in, e->stream, e->s_out}) HIP_TRY(e, hipStreamSynchronize(st));
+    return load_weights(e, policy, value);      // blocking copies into the buffers the kernels already point at
 }
 
 namespace {

@@ -58,6 +58,24 @@ class LeafEngine:
         if policy_sd is None and value_sd is None:
             raise TypeError("LeafEngine needs policy and/or value weights")
         lib = L.load()
+        pw, vw, keep = self._weight_structs(policy_sd, value_sd)
+        h = ctypes.c_void_p()
+        rc = lib.bk_engine_create(ctypes.byref(pw) if pw is not None else None,
+                                  ctypes.byref(vw) if vw is not None else None, int(device_id), int(max_batch),
+                                  ctypes.byref(h))
+        if rc != L.BK_OK:
+            raise RuntimeError(f"bk_engine_create failed: {L.STATUS_NAMES.get(rc, rc)}: "
+                               f"{lib.bk_last_error(None).decode()}")
+        self._lib, self._h = lib, h
+        self.device_id, self.max_batch = int(device_id), int(max_batch)
+        self.has_policy, self.has_value = policy_sd is not None, value_sd is not None
+        self._pending = {}
+        if precision is not None:
+            self.set_precision(precision)
+
+    @staticmethod
+    def _weight_structs(policy_sd, value_sd):
+        """state_dicts -> (bk_policy_weights | None, bk_value_weights | None, arrays to keep alive during the call)"""
         keep = []
         pw = vw = None
         if policy_sd is not None:
@@ -74,19 +92,17 @@ class LeafEngine:
                     raise ValueError(f"'{name}' has {a.size} elements, expected {size}")
                 keep.append(a)
                 setattr(vw.head, field, _ptr(a))
-        h = ctypes.c_void_p()
-        rc = lib.bk_engine_create(ctypes.byref(pw) if pw is not None else None,
-                                  ctypes.byref(vw) if vw is not None else None, int(device_id), int(max_batch),
-                                  ctypes.byref(h))
-        if rc != L.BK_OK:
-            raise RuntimeError(f"bk_engine_create failed: {L.STATUS_NAMES.get(rc, rc)}: "
-                               f"{lib.bk_last_error(None).decode()}")
-        self._lib, self._h = lib, h
-        self.device_id, self.max_batch = int(device_id), int(max_batch)
-        self.has_policy, self.has_value = policy_sd is not None, value_sd is not None
-        self._pending = {}
-        if precision is not None:
-            self.set_precision(precision)
+        return pw, vw, keep
+
+    def set_weights(self, policy_sd=None, value_sd=None):
+        """New weights into this engine (bk_engine_set_weights): what load_state_dict on a live net does.  A net left None
+        keeps its weights; every ticket must have been waited for."""
+        if self._pending:
+            raise RuntimeError("tickets outstanding: wait() for them before replacing the weights")
+        pw, vw, keep = self._weight_structs(policy_sd, value_sd)
+        self._check(self._lib.bk_engine_set_weights(self._h, ctypes.byref(pw) if pw is not None else None,
+                                                    ctypes.byref(vw) if vw is not None else None))
+        del keep
 
     def set_precision(self, precision):
         """'f32': exact fp32 MFMA; 'f16x2': fp16 hi/lo split operands, fp32 accumulation (faster)."""

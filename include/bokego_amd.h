@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 4
+#define BK_ABI_VERSION 5
 
 typedef enum bk_status {
     BK_OK = 0,
@@ -106,6 +106,17 @@ int bk_device_count(void);
 int bk_engine_create(const bk_policy_weights *policy, const bk_value_weights *value, int device_id,
                      int max_batch, bk_engine **out);
 int bk_engine_destroy(bk_engine *e);
+
+/*
+ * New weights into a live engine (ABI 5).  Replaces: an optimizer step on a module that keeps being called -- the
+ * reference's REINFORCE loop plays the next batch of games with the policy it has just updated
+ * (bin/selfplay.py:80-84 self_play(pi, ...), 117-119 optimizer.step()) -- and load_state_dict on a constructed net
+ * (boke.py:31-37).  A NULL net is left as it is; a net the engine was created without cannot be added.  Folding,
+ * packing and the copies happen before the call returns (~10 ms; creating an engine is 40-60 ms: streams, pinned
+ * slots); every later request sees the new weights.  No ticket may be outstanding (BK_ERR_ARG), and device-pointer
+ * calls the caller enqueued on its own streams must have completed.
+ */
+int bk_engine_set_weights(bk_engine *e, const bk_policy_weights *policy, const bk_value_weights *value);
 
 /*
  * Replaces: policy(fts) / v(fts) on host tensors (nnet.py:272-273, 283-284), batched.

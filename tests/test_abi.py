@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, f), f"{f} declared in include/bokego_amd.h but not exported"
         assert f in _lib.SYMBOLS, f"{f} has no ctypes prototype in bokego_amd/_lib.py"
     assert set(_lib.SYMBOLS) == set(fns)
-    assert lib.bk_abi_version() == 4
+    assert lib.bk_abi_version() == 5
 
 
 def test_plan_flops_counts_the_tile_tables(lib):

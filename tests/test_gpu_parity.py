@@ -653,3 +653,67 @@ def test_small_requests_without_copies_give_the_same_bits(weights, monkeypatch):
         assert got["value"].shape == (B,) and np.isfinite(got["value"]).all()
     assert eng.stats()["coop_fallbacks"] == 0
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_weights_replaced_in_a_live_engine(precision):
+    """bk_engine_set_weights (ABI 5): new weights into an engine that has already evaluated -- what an optimizer step or a
+    load_state_dict is to the reference's live modules (bin/selfplay.py:80-84,117-119; boke.py:31-37).  Every output bit
+    equals a fresh engine's created with those weights, for one net at a time and for both, on the small (cooperative),
+    the one-round and the split launch; with a ticket outstanding the call is refused and nothing changes."""
+    from bokego_amd.engine import LeafEngine
+    sets = _sweep_weight_sets()
+    x = np.load(os.path.join(GOLDEN, "sweep_worst.npz"))["features_A"]
+    x = np.concatenate([x] * (1 + 900 // len(x)))[:900].astype(np.uint8)
+    sizes = (5, 300, 900)
+
+    def run(eng):
+        return [eng.eval(x[:B], logits=True, probs=True, value=True) for B in sizes]
+
+    def same(a, b):
+        return all(np.array_equal(u[k], v[k]) for u, v in zip(a, b) for k in ("logits", "probs", "value"))
+
+    fresh = {}
+    for name, (pw, vw) in sets.items():
+        e = LeafEngine(pw, vw, max_batch=1024, precision=precision)
+        fresh[name] = run(e)
+        e.close()
+    e = LeafEngine(pw, vw, max_batch=1024, precision=precision)          # a fresh engine with policy A / value B
+    e.set_weights(policy_sd=sets["A"][0])
+    mixed = run(e)
+    e.close()
+    assert not same(fresh["A"], fresh["B"])
+
+    eng = LeafEngine(*sets["A"], max_batch=1024, precision=precision)
+    assert same(run(eng), fresh["A"])
+    eng.set_weights(value_sd=sets["B"][1])                                # one net at a time ...
+    assert same(run(eng), mixed)
+    eng.set_weights(policy_sd=sets["B"][0])
+    assert same(run(eng), fresh["B"])
+    eng.set_weights(*sets["A"])                                           # ... and both
+    assert same(run(eng), fresh["A"])
+    t = eng.submit(x[:40])
+    with pytest.raises(RuntimeError, match="outstanding"):
+        eng.set_weights(*sets["B"])
+    eng.wait(t)
+    assert same(run(eng), fresh["A"])
+    eng.close()
+
+
+def test_load_state_dict_reaches_a_fused_engine():
+    """HipPolicyNet.load_state_dict on a net whose engine is shared (nnet.fuse: what the batched MCTS evaluates through):
+    the shared engine takes the weights, so a search that holds it plays on with them -- the reference's modules behave
+    like that -- instead of the net silently leaving the engine behind."""
+    import torch
+    from bokego_amd import nnet
+    sets = _sweep_weight_sets()
+    x = torch.from_numpy(np.load(os.path.join(GOLDEN, "sweep_worst.npz"))["features_A"][:32].astype(np.float32))
+    pi, val = nnet.HipPolicyNet(sets["A"][0]), nnet.HipValueNet(sets["A"][1])
+    eng = nnet.fuse(pi, val)
+    a = pi(x).clone()
+    pi.load_state_dict(sets["B"][0])
+    assert pi.engine() is eng and val.engine() is eng
+    b = pi(x)
+    want = nnet.HipPolicyNet(sets["B"][0])(x)
+    assert torch.equal(b, want) and not torch.equal(a, b)
+    assert torch.equal(torch.from_numpy(eng.eval(x.numpy(), logits=True, probs=False, value=False)["logits"]), want)
