@@ -108,3 +108,17 @@ def test_simulation_mode_on_the_python_tree(nets):
     reply = g.send("genmove b")
     assert reply.startswith("= ") and reply.strip() not in ("=", "= resign")
     assert g.send("genmove w").startswith("= ")
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_timed_genmove_on_both_trees(nets, native):
+    """-t SEC (boke.py:15-16; gtp.py:357-358,368-372): with a time limit and no rollout count the search runs in
+    chunks until the time is up, then moves -- on the Python tree and on the native one."""
+    from bokego_amd.gtp import NativeGTP
+    from bokego_amd.mcts_native import Position
+    cls, root = (NativeGTP, Position()) if native else (GTP, Go_MCTS())
+    g = cls(root, nets[0], nets[1], no_sim=True, time_lim=0.15, expand_thresh=3)
+    g.running = True
+    reply = g.send("genmove b")
+    assert reply.startswith("= ") and 0.15 <= g.genmove_seconds[-1] < 5.0
+    assert g.send("genmove w").startswith("= ") and len(g._move_history) == 2
