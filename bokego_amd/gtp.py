@@ -6,7 +6,8 @@ bokego/gtp.py (GTP class, gtp.py:16-399) and a launcher that replaces boke.py.
 
 Differences from the reference, on purpose: `-r` is honoured (the reference parses it and drops
 it, boke.py:17 vs 40-44); `clear_cache` answers "= " instead of failing; pondering is off unless
-asked for (the reference ponders in a busy loop while a thread waits on stdin).
+asked for (`--ponder` / `pondering on`; the reference's default is on: it searches in a busy loop while a thread waits
+on stdin); an `analyze` reply ends with the empty line GTP requires once the next command has arrived.
 Replies are pinned against a transcript recorded from the reference (tests/golden/gtp_transcript.json).
 """
 import argparse
@@ -48,19 +49,64 @@ class _GTPProtocol:
 
     # ---- main loop ---------------------------------------------------------------------------------
     def start(self, stream_in=None, stream_out=None):
+        """The main loop (gtp.py:63-92).  On a live stream (stdin, a pipe: anything with a file descriptor) a thread reads
+        the commands, and while none is waiting the engine does what the reference's loop does: with pondering on it keeps
+        searching the current position (gtp.py:70-74), and after `analyze` it keeps printing info lines until the next
+        command arrives (gtp.py:77-86), then ends that reply with the empty line GTP asks for.  On an in-memory stream
+        (tests, replayed sessions) every command is already there: no thread, no pondering, one snapshot per `analyze`."""
         stream_in, stream_out = stream_in or sys.stdin, stream_out or sys.stdout
         self.running = True
-        for line in stream_in:
+
+        def write(text):
+            stream_out.write(text)
+            stream_out.flush()
+
+        try:
+            stream_in.fileno()
+            live = True
+        except (AttributeError, OSError, ValueError):
+            live = False
+        if live:
+            import queue
+            import threading
+            q = queue.Queue()
+
+            def reader():
+                for raw in stream_in:
+                    q.put(raw)
+                q.put(None)
+
+            threading.Thread(target=reader, daemon=True).start()
+
+            def lines():
+                while True:
+                    try:
+                        raw = q.get(timeout=0.0 if self.pondering else 0.25)
+                    except queue.Empty:
+                        if self.pondering and not self.root._terminal:
+                            self.rollout(10)              # think in the opponent's time (gtp.py:72-73)
+                        continue
+                    if raw is None:
+                        return
+                    yield raw
+            pending = lambda: not q.empty()  # noqa: E731
+        else:
+            lines = lambda: iter(stream_in)  # noqa: E731
+            pending = lambda: True           # noqa: E731
+        for line in lines():
             line = line.strip()
             if not line or line.startswith("#"):
                 continue
             out = self.send(line)
             if out is None:
                 break
-            if not isinstance(out, str):      # analyze generator: one snapshot, then the terminator
-                out = "".join([next(out), next(out), "\n"])
-            stream_out.write(out)
-            stream_out.flush()
+            if not isinstance(out, str):      # analyze: "= \n", info lines until a command is waiting, then the terminator
+                write(next(out))
+                write(next(out))
+                while not pending():
+                    write(next(out))
+                out = "\n"
+            write(out)
             if not self.running:
                 break
 

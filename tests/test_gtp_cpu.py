@@ -122,3 +122,53 @@ def test_timed_genmove_on_both_trees(nets, native):
     reply = g.send("genmove b")
     assert reply.startswith("= ") and 0.15 <= g.genmove_seconds[-1] < 5.0
     assert g.send("genmove w").startswith("= ") and len(g._move_history) == 2
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_live_stream_ponders_and_streams_analysis(nets, native):
+    """The reference's main loop on a live stream (gtp.py:63-92,374-399): with `pondering on` the engine searches while no
+    command is waiting, and `analyze` keeps printing info lines until the next command arrives, then ends its reply with an
+    empty line.  Commands come through a pipe with pauses in between, as a GUI sends them."""
+    import threading
+    import time
+    from bokego_amd.gtp import NativeGTP
+    from bokego_amd.mcts_native import Position
+    cls, root = (NativeGTP, Position()) if native else (GTP, Go_MCTS())
+    g = cls(root, nets[0], nets[1], no_sim=True, time_lim=None, n_rollouts=8, expand_thresh=3)
+    r, w = os.pipe()
+    rin, wout, out = os.fdopen(r, "r"), os.fdopen(w, "w"), io.StringIO()
+    t = threading.Thread(target=g.start, args=(rin, out))
+    t.start()
+
+    def send(cmd, replies=1):
+        """write a command and wait until its reply (a block ending in an empty line) is out"""
+        have = out.getvalue().count("\n\n")
+        wout.write(cmd + "\n")
+        wout.flush()
+        for _ in range(3000):
+            if out.getvalue().count("\n\n") >= have + replies:
+                return
+            time.sleep(0.01)
+        raise AssertionError(f"no reply to {cmd!r}: {out.getvalue()[-200:]!r}")
+
+    send("play b e5")
+    n0 = g.N[g.root]
+    send("pondering on")
+    time.sleep(1.0)
+    send("pondering off")
+    n1 = g.N[g.root]
+    time.sleep(0.5)
+    assert n1 > n0 and g.N[g.root] == n1                      # it searched while pondering was on, and only then
+    wout.write("analyze w 10\n")
+    wout.flush()
+    time.sleep(1.0)                                           # info lines keep coming ...
+    send("name", replies=2)                                   # ... until the next command: terminator, then its reply
+    send("quit")
+    wout.close()
+    t.join(timeout=30)
+    assert not t.is_alive()
+    text = out.getvalue()
+    body = text[text.rindex("= \ninfo"):text.index("= boke")]
+    lines = body.split("\n")
+    assert lines[0] == "= " and sum(ln.startswith("info move ") for ln in lines) >= 2, body
+    assert body.endswith("\n\n") and text.rstrip().endswith("=")          # analyze's terminator; quit's "= "
