@@ -132,6 +132,10 @@ class NativeMCTS:
             raise NotImplementedError("NativeMCTS implements the no-simulation mode only")
         if value_net is None and kwargs.get("evaluator") is None:
             raise TypeError("Keyword argument 'value_net' is required for no simulation mode")
+        if kwargs.get("branch_num"):
+            # mcts.py:189-190 (children = the legal moves among the policy's top k): the native tree expands every legal move;
+            # the Python tree (bokego_amd.mcts.MCTS) implements the restriction
+            raise NotImplementedError("NativeMCTS does not implement branch_num; use bokego_amd.mcts.MCTS")
         self.policy_net, self.value_net = policy_net, value_net
         self.expand_thresh = kwargs.get("expand_thresh", 100)
         self.exploration_weight = kwargs.get("exploration_weight", 4.0)

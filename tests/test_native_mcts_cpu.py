@@ -219,3 +219,12 @@ def test_best_prior_children_only_is_the_same_search_on_one_tree(speculate):
     info = {k: t._pool.info(0) for k, t in trees.items()}
     assert info[3]["n_value_evals"] < info[12]["n_value_evals"] < 0.6 * info[0]["n_value_evals"]
     assert NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True))._pool is not None     # default: every child (EAGER_TOP = 0)
+
+
+def test_unsupported_modes_are_refused_not_ignored():
+    """kwargs of the reference's MCTS that the native tree does not implement (simulation mode, mcts.py:58; branch_num,
+    mcts.py:62,189-190) raise instead of silently running a different search."""
+    with pytest.raises(NotImplementedError):
+        NativeMCTS(None, evaluator=object(), no_sim=False)
+    with pytest.raises(NotImplementedError):
+        NativeMCTS(None, evaluator=object(), branch_num=5)
