@@ -60,12 +60,13 @@ class _HipNet:
             extra = [k for k in state_dict if k not in sd and not k.endswith("num_batches_tracked")]
             if extra:
                 raise KeyError(f"unexpected keys in state_dict: {extra[:4]}")
-        self._sd = sd
         if self._engine is not None:
             # a live engine takes the new weights in place (bk_engine_set_weights) -- also when it is shared with the other net
             # (fuse()) or held by a running search's evaluator: everything that evaluates through it sees them from now on,
-            # as every caller of a torch module sees an optimizer step or a load_state_dict (bin/selfplay.py:80-84,117-119)
+            # as every caller of a torch module sees an optimizer step or a load_state_dict (bin/selfplay.py:80-84,117-119).
+            # Refused (RuntimeError, nothing changed) while the engine has tickets outstanding.
             self._engine.set_weights(**{"value_sd" if self._is_value else "policy_sd": sd})
+        self._sd = sd
         return self
 
     def state_dict(self):
