@@ -624,6 +624,8 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
     r["hbm"] = {"peak_GBps": PEAK_HBM_GBPS, "algorithmic_GBps": batch * BYTES_PER_LEAF / (kern_ms * 1e-3) / 1e9,
                 "measured_GBps": r["traffic"] / (kern_ms * 1e-3) / 1e9 if r["traffic"] else None}
     r["hbm"]["frac_measured"] = r["hbm"]["measured_GBps"] / PEAK_HBM_GBPS if r["hbm"]["measured_GBps"] else None
+    r["hbm"]["note"] = ("measured = (2 x FETCH_SIZE + WRITE_SIZE) per step: the L2s' requests to the fabric, Infinity-Cache hits included "
+                        "-- an upper bound on HBM bytes (both nets' workgroups read the planes; each XCD's L2 re-fetches its net's weights)")
     if live and live.get("executed_mfma_flop_per_launch"):
         r["pmc_executed_mfma_flop_per_launch"] = live["executed_mfma_flop_per_launch"]
     if f16:
