@@ -717,3 +717,25 @@ def test_load_state_dict_reaches_a_fused_engine():
     want = nnet.HipPolicyNet(sets["B"][0])(x)
     assert torch.equal(b, want) and not torch.equal(a, b)
     assert torch.equal(torch.from_numpy(eng.eval(x.numpy(), logits=True, probs=False, value=False)["logits"]), want)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_one_request_of_32768_positions(precision):
+    """A request eight times the benchmark's batch (21,846 workgroups, 72 MB of u8 planes): host-buffer and device-resident
+    entry points give, bit for bit, what the same positions give 4,096 at a time."""
+    import torch
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    base = make_batch(512, seed_base=777, dtype=np.uint8)
+    x = np.tile(base, (64, 1, 1, 1))[np.random.default_rng(1).permutation(32768)]
+    eng = LeafEngine(pw, vw, max_batch=32768, precision=precision)
+    parts = [eng.eval(x[i:i + 4096], logits=True, probs=True, value=True) for i in range(0, len(x), 4096)]
+    ref = {k: np.concatenate([p[k] for p in parts]) for k in ("logits", "probs", "value")}
+    big = eng.eval(x, logits=True, probs=True, value=True)
+    dev = eng.eval_device(torch.from_numpy(x).cuda(), logits=True, probs=True, value=True)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert np.array_equal(big[k].view(np.uint32), ref[k].view(np.uint32)), k
+        assert np.array_equal(dev[k].cpu().numpy().view(np.uint32), ref[k].view(np.uint32)), k
+    eng.close()
