@@ -64,6 +64,7 @@ def test_match_hip_engine_vs_cpu_backend_engine(tmp_path):
           f"HIP wins {first['boke-hip_wins']}/4")
 
 
+@pytest.mark.timeout(3300, method="thread")
 @pytest.mark.skipif(shutil.which("gnugo") is None, reason="no gnugo binary on this box (BASELINE configs[4] needs one)")
 def test_config4_vs_gnugo_runs_the_moment_gnugo_is_there(tmp_path):
     """BASELINE configs[4] as written.  Skips itself without a `gnugo`; with one it runs tools/run_cfg4.sh (100 games at
