@@ -619,6 +619,11 @@ public:
         static Team t;
         return t;
     }
+    // 0 on a calling thread, 1.. on the team's workers: stable for the life of the thread
+    static int& worker_id() {
+        static thread_local int id = 0;
+        return id;
+    }
     // fn(i) for i in [0, n) on up to `threads` threads (the caller is one of them); returns when all are done
     void run(int threads, int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
@@ -672,7 +677,10 @@ private:
         }
     }
     void grow(int workers) {
-        while ((int)th_.size() < workers && th_.size() < 63) th_.emplace_back([this] { loop(); });
+        while ((int)th_.size() < workers && th_.size() < 63) {
+            const int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id] { worker_id() = id; loop(); });
+        }
     }
     void loop() {
         unsigned long seen = 0;
@@ -697,8 +705,9 @@ private:
             {                                                  // nothing for 2 ms: sleep until the next job is announced
                 std::unique_lock<std::mutex> g(m_);
                 sleepers_.fetch_add(1, std::memory_order_seq_cst);
-                cv_.wait_for(g, std::chrono::milliseconds(50),
-                             [&] { return quit_.load() || announced_.load(std::memory_order_seq_cst) != seen; });
+                // (system_clock: pthread_cond_timedwait, which ThreadSanitizer intercepts -- `make tsan`; a clock step only moves one nap)
+                cv_.wait_until(g, std::chrono::system_clock::now() + std::chrono::milliseconds(50),
+                               [&] { return quit_.load() || announced_.load(std::memory_order_seq_cst) != seen; });
                 sleepers_.fetch_sub(1, std::memory_order_seq_cst);
             }
             idle_since = std::chrono::steady_clock::now();
@@ -728,11 +737,35 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
         p->row_cap = cap;
         for (auto& gm : p->games) gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
     }
-    Team::get().run(p->threads, G, [&](int g) {
+    auto advance_game = [&](int g) {
         Game& gm = p->games[g];
         if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
         else if (gm.has_request()) wants[g] = 1;
-    });
+    };
+    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
+    const int T = std::min(std::min(p->threads, G), 64);
+    if (lanes && T > 1) {
+        // A game is advanced by the same thread step after step, so its tree stays in that core's caches: lane L = games L,
+        // L + T, ...; a thread works off its own lane first (its stable id picks it), then helps with the others, so a thread
+        // that is late or missing costs nothing but the affinity.  Against handing out games one by one from a single counter:
+        // advance phase -10...-18 % on the EPYC host (tools/host_tree_bench.py), f16x2 self-play 0.50 -> 0.46 s per 512-game
+        // generation; fp32 is GPU-bound either way (profiles/r03_host_tree.txt).  BK_NO_LANES=1: the single counter.
+        std::atomic<int> cur[64];
+        for (int l = 0; l < T; ++l) cur[l].store(0, std::memory_order_relaxed);
+        Team::get().run(T, T, [&](int) {
+            const int mine = Team::worker_id() % T;
+            for (int d = 0; d < T; ++d) {
+                const int l = (mine + d) % T;
+                for (;;) {
+                    const int g = l + T * cur[l].fetch_add(1, std::memory_order_relaxed);
+                    if (g >= G) break;
+                    advance_game(g);
+                }
+            }
+        });
+    } else {
+        Team::get().run(p->threads, G, advance_game);
+    }
     const auto t1 = std::chrono::steady_clock::now();
     p->t_advance += std::chrono::duration<double>(t1 - t0).count();
     p->active.clear();

@@ -1,0 +1,67 @@
+// ThreadSanitizer driver of the game pools (bk_tree.cpp: worker team, lanes, emit phase): two pools of 48 games advanced in turn
+// with a fake evaluator, 6 threads each -- no Python, no GPU.   make -C bokego_amd/csrc tsan
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/bokego_go.h"
+#include "../../include/bokego_tree.h"
+
+int main() {
+    bk_search_params prm;
+    bk_search_params_default(&prm);
+    prm.rollouts = 60;
+    prm.expand_thresh = 8;
+    prm.noise_weight = 0.25f;
+    prm.sample_plies = 4;
+    prm.max_turns = 24;
+    prm.prune = 1;
+    prm.eager_top = 4;
+    constexpr int G = 48, CAP = 8192;
+    std::vector<uint64_t> seeds(G);
+    bk_pool* pools[2];
+    for (int p = 0; p < 2; ++p) {
+        for (int g = 0; g < G; ++g) seeds[g] = 20260 + 2 * g + p;
+        pools[p] = bk_pool_create(G, &prm, seeds.data(), 6);
+        if (!pools[p]) return 2;
+    }
+    std::vector<bk_pos> recs(CAP);
+    std::vector<float> probs((size_t)CAP * 81), values(CAP);
+    long steps = 0, rows = 0;
+    for (bool busy = true; busy;) {
+        busy = false;
+        for (int p = 0; p < 2; ++p) {
+            int npol = 0;
+            const int n = bk_pool_collect_pos(pools[p], recs.data(), CAP, &npol);
+            if (n == 0) continue;
+            busy = true;
+            for (int r = 0; r < npol; ++r) {
+                const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+                float sum = 0;
+                for (int k = 0; k < 81; ++k) sum += probs[(size_t)r * 81 + k] = 1.f + (float)((b[k] * 7 + k * 13 + r) % 17);
+                for (int k = 0; k < 81; ++k) probs[(size_t)r * 81 + k] /= sum;
+            }
+            for (int r = 0; r < n; ++r) {
+                const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+                unsigned h = 0;
+                for (int k = 0; k < 96; ++k) h = h * 31 + b[k];
+                values[r] = (float)(h % 2001) / 1000.f - 1.f;
+            }
+            bk_pool_deliver(pools[p], probs.data(), values.data());
+            ++steps;
+            rows += n;
+        }
+    }
+    long plies = 0;
+    for (int p = 0; p < 2; ++p) {
+        for (int g = 0; g < G; ++g) {
+            bk_game_info gi;
+            bk_pool_game_info(pools[p], g, &gi);
+            plies += gi.n_moves;
+        }
+        bk_pool_destroy(pools[p]);
+    }
+    std::printf("tsan_pool: %ld steps, %ld rows, %ld plies\n", steps, rows, plies);
+    return bk_team_selftest(4, 20000);
+}
