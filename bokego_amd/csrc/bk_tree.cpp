@@ -569,6 +569,7 @@ struct bk_pool {
     std::vector<int> active;      // games included in the last collect, in batch order
     std::vector<int> pol_off, val_off;
     int threads = 1;
+    std::vector<int> lane_items[64];   // scratch of run_lanes
 };
 
 extern "C" {
@@ -723,6 +724,39 @@ private:
     unsigned long last_id_ = 0;
 };
 
+// A game is worked on by the same thread step after step and phase after phase, so its tree stays in that core's caches: lane
+// L = games L, L + T, ... (T = threads taking part); a thread works off its own lane first (its stable id picks it), then helps
+// with the others, so a thread that is late or missing costs nothing but the affinity.  Items i in [0, n) belong to game
+// game_of(i).  Against handing items out one by one from a single counter: advance phase -10...-18 % on the EPYC host
+// (tools/host_tree_bench.py); deliveries, single-threaded before (they touched every tree from the calling thread, i.e. pulled
+// it out of its lane's caches), run in the lanes as well: f16x2 self-play 0.50 -> 0.42-0.44 s per 512-game generation.
+// BK_NO_LANES=1: the single counter (and serial deliveries).
+template <typename GameOf, typename Fn>
+void run_lanes(bk_pool* p, int n, GameOf game_of, Fn fn) {
+    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
+    const int T = std::min(std::min(p->threads, (int)p->games.size()), 64);
+    if (!lanes || T <= 1 || n <= 1) {
+        Team::get().run(T, n, fn);
+        return;
+    }
+    for (int l = 0; l < T; ++l) p->lane_items[l].clear();
+    for (int i = 0; i < n; ++i) p->lane_items[game_of(i) % T].push_back(i);
+    std::atomic<int> cur[64];
+    for (int l = 0; l < T; ++l) cur[l].store(0, std::memory_order_relaxed);
+    Team::get().run(T, T, [&](int) {
+        const int mine = Team::worker_id() % T;
+        for (int d = 0; d < T; ++d) {
+            const int l = (mine + d) % T;
+            const std::vector<int>& items = p->lane_items[l];
+            for (;;) {
+                const int k = cur[l].fetch_add(1, std::memory_order_relaxed);
+                if (k >= (int)items.size()) break;
+                fn(items[k]);
+            }
+        }
+    });
+}
+
 // advance every game to its next evaluation request and lay the batch out:
 // [policy nodes of every game ...][value nodes of every game ...]; games whose request does not fit under
 // `cap` keep it for the next collect.  emit(node position, row) writes one row of the batch.
@@ -742,30 +776,7 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
         if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
         else if (gm.has_request()) wants[g] = 1;
     };
-    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
-    const int T = std::min(std::min(p->threads, G), 64);
-    if (lanes && T > 1) {
-        // A game is advanced by the same thread step after step, so its tree stays in that core's caches: lane L = games L,
-        // L + T, ...; a thread works off its own lane first (its stable id picks it), then helps with the others, so a thread
-        // that is late or missing costs nothing but the affinity.  Against handing out games one by one from a single counter:
-        // advance phase -10...-18 % on the EPYC host (tools/host_tree_bench.py), f16x2 self-play 0.50 -> 0.46 s per 512-game
-        // generation; fp32 is GPU-bound either way (profiles/r03_host_tree.txt).  BK_NO_LANES=1: the single counter.
-        std::atomic<int> cur[64];
-        for (int l = 0; l < T; ++l) cur[l].store(0, std::memory_order_relaxed);
-        Team::get().run(T, T, [&](int) {
-            const int mine = Team::worker_id() % T;
-            for (int d = 0; d < T; ++d) {
-                const int l = (mine + d) % T;
-                for (;;) {
-                    const int g = l + T * cur[l].fetch_add(1, std::memory_order_relaxed);
-                    if (g >= G) break;
-                    advance_game(g);
-                }
-            }
-        });
-    } else {
-        Team::get().run(p->threads, G, advance_game);
-    }
+    run_lanes(p, G, [](int g) { return g; }, advance_game);
     const auto t1 = std::chrono::steady_clock::now();
     p->t_advance += std::chrono::duration<double>(t1 - t0).count();
     p->active.clear();
@@ -794,12 +805,14 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     }
     if (first_left >= 0) p->first = first_left;
     const int A = (int)p->active.size();
-    Team::get().run(npol + nval >= 64 ? p->threads : 1, A, [&](int a) {
+    auto emit_game = [&](int a) {
         Game& gm = p->games[p->active[a]];
         for (size_t i = 0; i < gm.req_policy.size(); ++i) emit(&gm.poses[gm.req_policy[i]], (size_t)(p->pol_off[a] + i));
         for (size_t i = 0; i < gm.req_value.size(); ++i) emit(&gm.poses[gm.req_value[i]], (size_t)(npol + p->val_off[a] + i));
         gm.n_requests += 1;
-    });
+    };
+    if (npol + nval >= 64) run_lanes(p, A, [&](int a) { return p->active[a]; }, emit_game);
+    else for (int a = 0; a < A; ++a) emit_game(a);
     p->t_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     *n_policy = npol;
     return npol + nval;
@@ -864,11 +877,13 @@ void bk_pool_phase_seconds(const bk_pool* p, double* out3) {   // advance, emit,
 
 void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
     const auto t0 = std::chrono::steady_clock::now();
-    int npol = 0;
-    for (size_t a = 0; a < p->active.size(); ++a) npol += (int)p->games[p->active[a]].req_policy.size();
+    int npol = 0, nval = 0;
+    for (size_t a = 0; a < p->active.size(); ++a) {
+        npol += (int)p->games[p->active[a]].req_policy.size();
+        nval += (int)p->games[p->active[a]].req_value.size();
+    }
     const int A = (int)p->active.size();
-    // a delivery is a few hundred table writes: one thread (a parallel phase cost more than it saved)
-    for (int a = 0; a < A; ++a) {
+    auto deliver_game = [&](int a) {
         Game& gm = p->games[p->active[a]];
         for (size_t i = 0; i < gm.req_policy.size(); ++i) {
             const int row = p->pol_off[a] + (int)i;
@@ -878,7 +893,11 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
         for (size_t i = 0; i < gm.req_value.size(); ++i) gm.deliver_value(gm.req_value[i], values[npol + p->val_off[a] + (int)i]);
         gm.req_policy.clear();
         gm.req_value.clear();
-    }
+    };
+    // in the games' lanes (with a single hand-out counter a parallel delivery cost more than it saved; BK_NO_LANES keeps it serial)
+    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
+    if (lanes && npol + nval >= 64) run_lanes(p, A, [&](int a) { return p->active[a]; }, deliver_game);
+    else for (int a = 0; a < A; ++a) deliver_game(a);
     p->active.clear();
     p->t_deliver += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
