@@ -1,5 +1,6 @@
 // ThreadSanitizer driver of the game pools (bk_tree.cpp: worker team, lanes, emit phase): two pools of 48 games advanced in turn
 // with a fake evaluator, 6 threads each -- no Python, no GPU.   make -C bokego_amd/csrc tsan
+// Also the gprof driver of the host side: tsan_pool [games per pool] [rollouts] [expand_thresh] [max_turns] [threads]
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -8,22 +9,25 @@
 #include "../../include/bokego_go.h"
 #include "../../include/bokego_tree.h"
 
-int main() {
+#include <cstdlib>
+int main(int argc, char** argv) {
     bk_search_params prm;
     bk_search_params_default(&prm);
-    prm.rollouts = 60;
-    prm.expand_thresh = 8;
+    const int G = argc > 1 ? atoi(argv[1]) : 48;
+    prm.rollouts = argc > 2 ? atoi(argv[2]) : 60;
+    prm.expand_thresh = argc > 3 ? atoi(argv[3]) : 8;
     prm.noise_weight = 0.25f;
     prm.sample_plies = 4;
-    prm.max_turns = 24;
+    prm.max_turns = argc > 4 ? atoi(argv[4]) : 24;
     prm.prune = 1;
     prm.eager_top = 4;
-    constexpr int G = 48, CAP = 8192;
+    const int threads = argc > 5 ? atoi(argv[5]) : 6;
+    constexpr int CAP = 8192;
     std::vector<uint64_t> seeds(G);
     bk_pool* pools[2];
     for (int p = 0; p < 2; ++p) {
         for (int g = 0; g < G; ++g) seeds[g] = 20260 + 2 * g + p;
-        pools[p] = bk_pool_create(G, &prm, seeds.data(), 6);
+        pools[p] = bk_pool_create(G, &prm, seeds.data(), threads);
         if (!pools[p]) return 2;
     }
     std::vector<bk_pos> recs(CAP);
