@@ -838,6 +838,9 @@ def main():
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
               "search": "an expansion evaluates its best-prior children only (bk_search_params.eager_top), the rest when a rollout "
                         "reaches it: the same 512 games as with every child evaluated (rounds 1-2), 3.4 M -> 0.7 M evaluations"}
+        # untimed: a small generation first (the pools' worker threads exist, the allocator and the caches are warm)
+        selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=min(64 * world, args.selfplay_games), rollouts=50, rank=rank, world=world,
+                           cap=8192, threads=threads, reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
         for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
             eng.set_precision(prec)
             ev = selfplay.EngineEvaluator(eng)
