@@ -341,7 +341,10 @@ def launch_plan(n, allowed=None, gpu_nodes=None, node_cpus=None, quota=None, dev
         else:
             cpus = pool[k * len(pool) // len(peers):(k + 1) * len(pool) // len(peers)] or pool
         threads = max(1, min(threads_cap, len(cpus), (quota // n) if quota else len(cpus)))
-        threads = max(1, threads - 4 if threads > 8 else threads)    # the pools' workers spin: leave room for Python and the HIP runtime
+        # the pools' workers spin, and beside them the HIP runtime keeps one thread busy (tools/cpu_use_probe.py: 12 host
+        # threads = 12.7 CPUs): leave room for it and for Python -- 4 CPUs of a large share, 1 of a small one (a rank that
+        # owns 2 CPUs' worth of a cgroup quota runs its pools on the calling thread alone)
+        threads = max(1, threads - 4 if threads > 8 else threads - 1)
         ranks.append({"rank": r, "local_rank": r, "device": devs[r], "numa_node": nd, "cpus": format_cpulist(cpus),
                       "n_cpus": len(cpus), "host_threads": threads})
     return {"world": n, "ranks": ranks, "cpus_allowed": len(allowed), "cgroup_cpu_quota": quota,

@@ -70,7 +70,11 @@ def test_launch_plan_splits_whole_cores_by_numa_node():
     # one-GPU rehearsal: every rank opens the same device; the quota bounds the threads
     reh = bench.launch_plan(2, allowed=range(256), gpu_nodes=[1], node_cpus=node_cpus, quota=16, device=0,
                             core_of={c: c % 128 for c in range(256)})
-    assert [r["device"] for r in reh["ranks"]] == [0, 0] and [r["host_threads"] for r in reh["ranks"]] == [8, 8]
+    assert [r["device"] for r in reh["ranks"]] == [0, 0] and [r["host_threads"] for r in reh["ranks"]] == [7, 7]   # 8 CPUs' worth each, one left to the HIP runtime
+    # eight ranks under a 16-CPU quota: 2 CPUs' worth each -> the pools run on the calling thread alone
+    tight = bench.launch_plan(8, allowed=range(256), gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], node_cpus=node_cpus, quota=16,
+                              core_of={c: c % 128 for c in range(256)})
+    assert [r["host_threads"] for r in tight["ranks"]] == [1] * 8
     assert all(r["numa_node"] == 1 for r in reh["ranks"])
 
 
