@@ -835,7 +835,10 @@ def main():
         from bokego_amd import selfplay
         # host cores are shared by the ranks: a launch() child got its slice and thread count from the plan, a
         # torch.distributed.run rank sees every CPU and takes 1/world of them (of the cgroup quota when there is one)
-        threads = int(os.environ.get("BK_BENCH_HOST_THREADS", 0)) or max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
+        threads = int(os.environ.get("BK_BENCH_HOST_THREADS", 0))
+        if not threads:
+            share = max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
+            threads = max(1, share - 4 if share > 8 else share - 1)      # as launch_plan: room for the HIP runtime's thread
         threads = max(1, min(12, threads, (args.selfplay_games // world) // 16 or 1))    # <= one per 8 games of a pool (two pools): selfplay.default_threads
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
