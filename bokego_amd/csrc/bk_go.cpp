@@ -440,12 +440,66 @@ void bk_features_batch_u8(void* pos, int n, int stride, uint8_t* out, int fresh)
         features_impl(reinterpret_cast<bk_pos*>(static_cast<char*>(pos) + (size_t)i * stride), out + (size_t)i * 2187, fresh);
 }
 
-int bk_pos_children(const bk_pos* p, bk_pos* out, int16_t* moves) {
+// every legal successor, one bk_pos_play each: the definition (and what tests compare bk_pos_children with)
+int bk_pos_children_slow(const bk_pos* p, bk_pos* out, int16_t* moves) {
     int n = 0;
     for (int s = 0; s < NN; ++s) {
         if (p->board[s] != BK_EMPTY || s == p->ko) continue;
         out[n] = *p;
         if (bk_pos_play(&out[n], s) == 0) moves[n++] = (int16_t)s;
+    }
+    return n;
+}
+
+// The same successors without a flood fill per candidate and neighbour (an expansion of the tree search builds ~75 of them:
+// chain_at was 16 % of the host side of self-play).  The position's chains and their exact liberty counts are found once;
+// the liberty cache is refreshed once (every successor inherits the parent's cache as refreshed before the move, go.py:160).
+// A move next to no opponent chain in atari captures nothing: it is legal iff the point has an empty neighbour or joins a chain of
+// its own colour that has another liberty, the new board is the old one plus the stone, and no ko arises (a ko needs exactly one
+// captured stone).  Only moves that may capture take the general path.
+int bk_pos_children(const bk_pos* p, bk_pos* out, int16_t* moves) {
+    bk_pos base = *p;
+    refresh_libs(&base);
+    int8_t cid[NN];
+    uint8_t clibs[NN];
+    std::memset(cid, -1, NN);
+    int nc = 0;
+    Chain ch;
+    for (int s = 0; s < NN; ++s) {
+        if (base.board[s] == BK_EMPTY || cid[s] >= 0) continue;
+        chain_at(base.board, s, ch);
+        for (int i = 0; i < ch.n; ++i) cid[ch.stones[i]] = (int8_t)nc;
+        clibs[nc++] = (uint8_t)ch.nlibs;
+    }
+    const int8_t color = (base.turn & 1) ? BK_WHITE : BK_BLACK;
+    const int8_t opp = color == BK_WHITE ? BK_BLACK : BK_WHITE;
+    uint64_t h0 = base.hash ^ T.flip;
+    if (base.ko >= 0) h0 ^= T.z[2][base.ko];
+    int n = 0;
+    for (int s = 0; s < NN; ++s) {
+        if (base.board[s] != BK_EMPTY || s == base.ko) continue;
+        bool may_capture = false, alive = false;
+        for (int k = 0; k < T.nn[s]; ++k) {
+            const int t = T.nbr[s][k];
+            const int8_t b = base.board[t];
+            if (b == BK_EMPTY) alive = true;
+            else if (b == opp) may_capture = may_capture || clibs[cid[t]] == 1;
+            else alive = alive || clibs[cid[t]] >= 2;
+        }
+        if (may_capture) {
+            out[n] = base;
+            if (bk_pos_play(&out[n], s) == 0) moves[n++] = (int16_t)s;
+            continue;
+        }
+        if (!alive) continue;                       // suicide
+        bk_pos& c = out[n];
+        c = base;
+        c.board[s] = color;
+        c.hash = h0 ^ T.z[color - 1][s];
+        c.last_move = (int16_t)s;
+        c.ko = BK_NO_KO;
+        c.turn += 1;
+        moves[n++] = (int16_t)s;
     }
     return n;
 }

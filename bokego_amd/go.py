@@ -47,6 +47,7 @@ GO_SYMBOLS = {
     "bk_pos_features_f32": (None, [_PP, ctypes.c_void_p, ctypes.c_int]),
     "bk_features_batch_u8": (None, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     "bk_pos_children": (ctypes.c_int, [_PP, ctypes.c_void_p, ctypes.c_void_p]),
+    "bk_pos_children_slow": (ctypes.c_int, [_PP, ctypes.c_void_p, ctypes.c_void_p]),
 }
 _golib = None
 

@@ -83,6 +83,9 @@ void bk_features_batch_u8(void *pos, int n, int stride, uint8_t *out, int fresh)
 /* children of a node: for every legal move (ascending index) a copy of *p with the move played
  * (Go_MCTS.find_children, mcts.py:309-317).  Returns the number written to out/moves (<= 81). */
 int bk_pos_children(const bk_pos *p, bk_pos *out, int16_t *moves);
+/* the same by definition -- one bk_pos_play per empty point; bk_pos_children finds the position's chains once instead
+ * (tests compare the two record for record) */
+int bk_pos_children_slow(const bk_pos *p, bk_pos *out, int16_t *moves);
 
 #ifdef __cplusplus
 }

@@ -127,3 +127,37 @@ def test_score_area():
     assert go.Game(board=b).score() == 36 - (36 + 5.5)
     b = "X" * 36 + "." * 45
     assert go.Game(board=b).score() == 81 - 5.5
+
+
+def test_children_without_a_flood_fill_per_move_equal_the_definition():
+    """bk_pos_children finds a position's chains once and builds the successors of non-capturing moves directly; the definition
+    is one bk_pos_play per empty point (bk_pos_children_slow).  Record for record -- board, ko, hash, turn, last move, liberty
+    cache -- over random playouts (captures, kos, suicides, passes, stale liberty caches included), 20,000+ positions."""
+    import ctypes
+    lib = go.golib()
+    rng = np.random.default_rng(5)
+    checked = caps = 0
+    for game in range(400):
+        pos = go.Pos()
+        lib.bk_pos_init(ctypes.byref(pos))
+        for ply in range(int(rng.integers(5, 110))):
+            a, b = (go.Pos * 81)(), (go.Pos * 81)()
+            ma, mb = (ctypes.c_int16 * 81)(), (ctypes.c_int16 * 81)()
+            na = lib.bk_pos_children(ctypes.byref(pos), a, ma)
+            nb = lib.bk_pos_children_slow(ctypes.byref(pos), b, mb)
+            assert na == nb and list(ma[:na]) == list(mb[:nb])
+            assert bytes(a)[:192 * na] == bytes(b)[:192 * nb]
+            checked += 1
+            if na == 0:
+                break
+            stones = sum(1 for c in bytes(pos)[:81] if c)
+            k = int(rng.integers(0, na))
+            if rng.random() < 0.03:
+                lib.bk_pos_play(ctypes.byref(pos), go.PASS)
+            else:
+                pos = go.Pos.from_buffer_copy(a[k])
+                caps += sum(1 for c in bytes(pos)[:81] if c) <= stones
+            if rng.random() < 0.2:                      # a feature request refreshes the liberty cache in between
+                libs = (ctypes.c_uint8 * 81)()
+                lib.bk_pos_liberties(ctypes.byref(pos), libs)
+    assert checked > 20000 and caps > 300
