@@ -80,10 +80,11 @@ class _GTPProtocol:
 
             def lines():
                 while True:
+                    ponder = self.pondering and not self.root._terminal
                     try:
-                        raw = q.get(timeout=0.0 if self.pondering else 0.25)
+                        raw = q.get(block=not ponder, timeout=None if ponder else 0.25)
                     except queue.Empty:
-                        if self.pondering and not self.root._terminal:
+                        if ponder:
                             self.rollout(10)              # think in the opponent's time (gtp.py:72-73)
                         continue
                     if raw is None:
