@@ -15,10 +15,13 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <pthread.h>
 #include <unordered_map>
 #include <vector>
 
@@ -173,6 +176,10 @@ struct Game {
         return (cur + 255) / 256 * 256;   // beyond the last step: whole rounds of one-CU workgroups
     }
     bool fits(int extra_tasks) const { return prm.request_tasks <= 0 || request_tasks() + extra_tasks <= ceiling(); }
+    // rows one collect can take (the pool's smallest `cap`): passengers -- spilled values, speculative rows -- never push a
+    // request beyond it; a request that cannot fit would be skipped by every collect and its game would stall
+    int row_cap = 1 << 30;
+    bool room_for_rows(int extra_rows) const { return (int)(req_policy.size() + req_value.size()) + extra_rows <= row_cap; }
     bool queued_value(int c) const { return std::find(req_value.begin(), req_value.end(), c) != req_value.end(); }
     // children (node ids) that still lack a value and are not in the request, most promising first when the parent's priors are
     // known (the search visits high priors first), else in move order
@@ -214,7 +221,7 @@ struct Game {
             // first: every child goes now.  With known priors (the node was evaluated ahead) the tail may wait.
             const bool may_wait = prm.request_tasks > 0 && nodes[id].has_prior;
             for (int c : wanting(kidv, id)) {
-                if (!may_wait || fits(1)) req_value.push_back(c);
+                if (!may_wait || (fits(1) && room_for_rows(1))) req_value.push_back(c);
                 else spill.push_back(c);
             }
         }
@@ -322,7 +329,7 @@ struct Game {
             std::vector<int> left;
             for (int c : spill) {
                 if (nodes[c].has_value || queued_value(c)) continue;
-                if (fits(1)) req_value.push_back(c);
+                if (fits(1) && room_for_rows(1)) req_value.push_back(c);
                 else left.push_back(c);
             }
             spill.swap(left);
@@ -614,115 +621,203 @@ namespace {
 // (profiles/r03_host_tree.txt).  This team keeps its workers spinning for a while after a job (the next one comes within a
 // fraction of a millisecond while a generation runs), lets them sleep when nothing has come for 2 ms, and hands out items
 // one by one from an atomic counter (a game that has to expand a node takes 100x longer than one that does not).
+// Several callers at once (two pools driven from two Python threads: two engines in one process) each publish their job in a
+// slot of their own and the workers serve every slot they find occupied, so the jobs run side by side instead of taking
+// turns; the team grows to the helpers all running jobs ask for together.
+inline void cpu_relax() {                           // the spin-wait hint of the host's CPU (the library builds on any host)
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 class Team {
 public:
     static Team& get() {
-        static Team t;
-        return t;
+        Team* t = instance_.load(std::memory_order_acquire);
+        if (t) return *t;
+        std::lock_guard<std::mutex> g(create_m());
+        t = instance_.load(std::memory_order_acquire);
+        if (!t) {
+            t = new Team();
+            instance_.store(t, std::memory_order_release);
+            static bool hooked = false;
+            if (!hooked) {
+                hooked = true;
+                // fork(): the child inherits the team's state but none of its threads (a worker caught between inside++ and
+                // inside-- would be waited for for ever, sleepers would be counted that do not exist): the child starts with a
+                // fresh team; the old one is left alone (its mutexes may be held by threads that are not there).
+                pthread_atfork(nullptr, nullptr, [] { instance_.store(nullptr, std::memory_order_release); new (&create_m()) std::mutex(); });
+                std::atexit([] {
+                    if (Team* cur = instance_.load(std::memory_order_acquire)) cur->shutdown();
+                });
+            }
+        }
+        return *t;
     }
     // 0 on a calling thread, 1.. on the team's workers: stable for the life of the thread
     static int& worker_id() {
         static thread_local int id = 0;
         return id;
     }
-    // fn(i) for i in [0, n) on up to `threads` threads (the caller is one of them); returns when all are done
+    // fn(i) for i in [0, n) on up to `threads` threads (the caller is one of them); returns when all are done.  An exception
+    // thrown by fn on any thread is rethrown here, after every item has been handed out.
     void run(int threads, int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         if (threads <= 1 || n == 1) {
             for (int i = 0; i < n; ++i) fn(i);
             return;
         }
-        std::lock_guard<std::mutex> serial(run_m_);            // pools of different Python threads take turns
-        grow(threads - 1);
-        Job job{&fn, n, threads - 1};
-        job.id = ++last_id_;
+        const int helpers = std::min(threads - 1, kMaxWorkers);
+        Slot* sl = nullptr;
+        for (int spins = 0; !sl; ++spins) {                    // a free slot (more than kSlots callers at once: wait for one)
+            for (auto& c : slots_) {
+                bool free_ = false;
+                if (c.taken.compare_exchange_strong(free_, true, std::memory_order_acquire)) { sl = &c; break; }
+            }
+            if (!sl) { if (spins < 64) cpu_relax(); else std::this_thread::yield(); }
+        }
+        grow(demand_.fetch_add(helpers, std::memory_order_relaxed) + helpers);
+        Job job;
+        job.fn = &fn;
+        job.n = n;
+        job.helpers = helpers;
+        job.id = last_id_.fetch_add(1, std::memory_order_relaxed) + 1;
         // Publishing and retiring a job are store-then-load hand-shakes with the workers (Dekker-style): the caller stores
-        // cur_ / announced_ and then reads inside_ / sleepers_, a worker raises inside_ / sleepers_ and then reads cur_ /
+        // cur / announced_ and then reads inside / sleepers_, a worker raises inside / sleepers_ and then reads cur /
         // announced_.  Each side must see the other's store or be seen by it, which only sequentially consistent
         // operations give (with release/acquire the caller's load may pass its own store: a late worker then walked into
         // a job whose stack frame was gone -- a rare segfault in whatever the calling thread did next).
-        cur_.store(&job, std::memory_order_seq_cst);
-        announced_.store(job.id, std::memory_order_seq_cst);     // what sleepers watch (they must not look into `job`)
+        sl->cur.store(&job, std::memory_order_seq_cst);
+        announced_.fetch_add(1, std::memory_order_seq_cst);      // what sleepers watch (they must not look into `job`)
         if (sleepers_.load(std::memory_order_seq_cst) > 0) {
             std::lock_guard<std::mutex> g(m_);
             cv_.notify_all();
         }
         work(job);
         while (job.done.load(std::memory_order_acquire) < n) cpu_relax();
-        cur_.store(nullptr, std::memory_order_seq_cst);
-        while (inside_.load(std::memory_order_seq_cst) != 0) cpu_relax();   // nobody still looks at `job`
+        sl->cur.store(nullptr, std::memory_order_seq_cst);
+        while (sl->inside.load(std::memory_order_seq_cst) != 0) cpu_relax();   // nobody still looks at `job`
+        demand_.fetch_sub(helpers, std::memory_order_relaxed);
+        sl->taken.store(false, std::memory_order_release);
+        if (job.failed.load(std::memory_order_acquire)) std::rethrow_exception(job.error);
     }
-    ~Team() {
+
+private:
+    static constexpr int kSlots = 8, kMaxWorkers = 63;
+    struct Job {
+        const std::function<void(int)>* fn = nullptr;
+        int n = 0, helpers = 0;
+        unsigned long id = 0;
+        std::atomic<int> next{0}, done{0}, joined{0};
+        std::atomic<bool> failed{false};
+        std::exception_ptr error;
+    };
+    struct alignas(64) Slot {
+        std::atomic<Job*> cur{nullptr};
+        std::atomic<int> inside{0};
+        std::atomic<bool> taken{false};
+    };
+    static std::mutex& create_m() {
+        static std::mutex* m = new std::mutex();    // never destroyed: get() may run during static destruction
+        return *m;
+    }
+    static void work(Job& j) {
+        for (;;) {
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) break;
+            try {
+                (*j.fn)(i);
+            } catch (...) {                                    // the item counts as done (the caller must not wait for ever);
+                bool first = false;                            // the first exception travels to the caller
+                if (j.failed.compare_exchange_strong(first, true, std::memory_order_acq_rel)) j.error = std::current_exception();
+            }
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void grow(int workers) {
+        workers = std::min(workers, kMaxWorkers);
+        if (n_threads_.load(std::memory_order_acquire) >= workers) return;
+        std::lock_guard<std::mutex> g(grow_m_);
+        while ((int)th_.size() < workers) {
+            const int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id] { worker_id() = id; loop(); });
+        }
+        n_threads_.store((int)th_.size(), std::memory_order_release);
+    }
+    void shutdown() {
         quit_.store(true);
         {
             std::lock_guard<std::mutex> g(m_);
             cv_.notify_all();
         }
+        std::lock_guard<std::mutex> g(grow_m_);
         for (auto& t : th_) t.join();
-    }
-
-private:
-    struct Job {
-        const std::function<void(int)>* fn;
-        int n, helpers;
-        unsigned long id = 0;
-        std::atomic<int> next{0}, done{0}, joined{0};
-    };
-    static void cpu_relax() { __builtin_ia32_pause(); }
-    static void work(Job& j) {
-        for (;;) {
-            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= j.n) break;
-            (*j.fn)(i);
-            j.done.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void grow(int workers) {
-        while ((int)th_.size() < workers && th_.size() < 63) {
-            const int id = (int)th_.size() + 1;
-            th_.emplace_back([this, id] { worker_id() = id; loop(); });
-        }
+        th_.clear();
     }
     void loop() {
-        unsigned long seen = 0;
+        unsigned long seen[kSlots] = {0};
         auto idle_since = std::chrono::steady_clock::now();
         int spins = 0;
+        bool napping = false;
         while (!quit_.load(std::memory_order_relaxed)) {
-            inside_.fetch_add(1, std::memory_order_seq_cst);
-            Job* j = cur_.load(std::memory_order_seq_cst);
-            if (j && j->id != seen) {
-                seen = j->id;
-                if (j->joined.fetch_add(1, std::memory_order_relaxed) < j->helpers) work(*j);
-                inside_.fetch_sub(1, std::memory_order_seq_cst);
+            // what the sleep below waits to see CHANGE: taken before the look at the slots, so a job announced after this
+            // line keeps the worker awake, and one announced before it is found in its slot (or is retired already).  (The
+            // predicate used to be "announced != the last job I joined": a worker that had missed a short job -- asleep, or
+            // descheduled under a CPU quota -- then never slept again and spun at 100 % CPU between generations: ADVICE r3.)
+            const unsigned long a = announced_.load(std::memory_order_seq_cst);
+            bool worked = false;
+            for (int k = 0; k < kSlots; ++k) {
+                Slot& sl = slots_[k];
+                if (!sl.cur.load(std::memory_order_relaxed)) continue;   // a hint only: the hand-shake is below
+                sl.inside.fetch_add(1, std::memory_order_seq_cst);
+                Job* j = sl.cur.load(std::memory_order_seq_cst);
+                if (j && j->id != seen[k]) {
+                    seen[k] = j->id;
+                    if (j->joined.fetch_add(1, std::memory_order_relaxed) < j->helpers) {
+                        work(*j);
+                        worked = true;
+                    }
+                }
+                sl.inside.fetch_sub(1, std::memory_order_seq_cst);
+            }
+            if (worked) {
                 idle_since = std::chrono::steady_clock::now();
                 spins = 0;
+                napping = false;
                 continue;
             }
-            inside_.fetch_sub(1, std::memory_order_seq_cst);
-            cpu_relax();
-            if (++spins < 2000) continue;                      // ~a few microseconds between looks at the clock
-            spins = 0;
-            if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(2)) continue;
+            if (!napping) {                                    // (a nap that merely timed out is followed by the next nap, not by 2 ms of spinning)
+                cpu_relax();
+                if (++spins < 2000) continue;                  // ~a few microseconds between looks at the clock
+                spins = 0;
+                if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(2)) continue;
+            }
             {                                                  // nothing for 2 ms: sleep until the next job is announced
                 std::unique_lock<std::mutex> g(m_);
                 sleepers_.fetch_add(1, std::memory_order_seq_cst);
                 // (system_clock: pthread_cond_timedwait, which ThreadSanitizer intercepts -- `make tsan`; a clock step only moves one nap)
                 cv_.wait_until(g, std::chrono::system_clock::now() + std::chrono::milliseconds(50),
-                               [&] { return quit_.load() || announced_.load(std::memory_order_seq_cst) != seen; });
+                               [&] { return quit_.load() || announced_.load(std::memory_order_seq_cst) != a; });
                 sleepers_.fetch_sub(1, std::memory_order_seq_cst);
             }
+            napping = announced_.load(std::memory_order_seq_cst) == a;   // timed out: look at the slots once and sleep on
             idle_since = std::chrono::steady_clock::now();
         }
     }
+    static std::atomic<Team*> instance_;
+    Slot slots_[kSlots];
     std::vector<std::thread> th_;
-    std::mutex m_, run_m_;
+    std::atomic<int> n_threads_{0}, demand_{0};
+    std::mutex m_, grow_m_;
     std::condition_variable cv_;
-    std::atomic<Job*> cur_{nullptr};
-    std::atomic<int> inside_{0}, sleepers_{0};
-    std::atomic<unsigned long> announced_{0};
+    std::atomic<int> sleepers_{0};
+    std::atomic<unsigned long> announced_{0}, last_id_{0};
     std::atomic<bool> quit_{false};
-    unsigned long last_id_ = 0;
 };
+std::atomic<Team*> Team::instance_{nullptr};
 
 // A game is worked on by the same thread step after step and phase after phase, so its tree stays in that core's caches: lane
 // L = games L, L + T, ... (T = threads taking part); a thread works off its own lane first (its stable id picks it), then helps
@@ -769,7 +864,10 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
         // a request grows by speculative rows up to prm.speculate_rows: never beyond what one collect can take (a request
         // that cannot fit would be skipped for ever: ADVICE r2).  A request without speculation is <= 82 rows <= cap.
         p->row_cap = cap;
-        for (auto& gm : p->games) gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
+        for (auto& gm : p->games) {
+            gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
+            gm.row_cap = cap;
+        }
     }
     auto advance_game = [&](int g) {
         Game& gm = p->games[g];
@@ -854,7 +952,7 @@ __attribute__((noinline)) int team_region(int threads, int n) {
 __attribute__((noinline)) int team_canary(int spins) {
     volatile unsigned char pad[768];
     for (auto& b : pad) b = 0xA5;
-    for (int i = 0; i < spins; ++i) __builtin_ia32_pause();
+    for (int i = 0; i < spins; ++i) cpu_relax();
     for (auto& b : pad)
         if (b != 0xA5) return 1;
     return 0;
@@ -867,6 +965,28 @@ int bk_team_selftest(int threads, int jobs) {
         if (k % 4096 == 4095) std::this_thread::sleep_for(std::chrono::milliseconds(3));
     }
     return 0;
+}
+
+// Two callers at once: each runs one region whose items wait (bounded) until they have seen the OTHER caller's region running.
+// A team that lets its callers take turns cannot finish this: returns 0 when both regions met, 1 when they did not within
+// `timeout_ms` (the regions then give up, so the call always returns).
+int bk_team_selftest_concurrent(int threads, int timeout_ms) {
+    std::atomic<int> up[2] = {{0}, {0}}, met[2] = {{0}, {0}};
+    auto caller = [&](int me) {
+        Team::get().run(threads, threads, [&](int) {
+            up[me].store(1, std::memory_order_seq_cst);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!up[1 - me].load(std::memory_order_seq_cst)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return;
+                cpu_relax();
+            }
+            met[me].store(1, std::memory_order_seq_cst);
+        });
+    };
+    std::thread a(caller, 0), b(caller, 1);
+    a.join();
+    b.join();
+    return met[0].load() && met[1].load() ? 0 : 1;
 }
 
 void bk_pool_phase_seconds(const bk_pool* p, double* out3) {   // advance, emit, deliver

@@ -56,6 +56,7 @@ TREE_SYMBOLS = {
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
     "bk_pool_phase_seconds": (None, [_VP, _VP]),
     "bk_team_selftest": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "bk_team_selftest_concurrent": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "bk_pool_set_task_cap": (None, [_VP, ctypes.c_int]),
     "bk_pool_n_games": (ctypes.c_int, [_VP]),
     "bk_pool_n_done": (ctypes.c_int, [_VP]),

@@ -113,6 +113,8 @@ void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 void bk_pool_phase_seconds(const bk_pool *p, double *out3);
 /* stress of the worker threads the pools share (`jobs` short parallel regions on `threads` threads); 0 = every item ran once */
 int bk_team_selftest(int threads, int jobs);
+/* two callers at once, each with a region that waits (at most timeout_ms) to see the other's running: 0 = they ran side by side */
+int bk_team_selftest_concurrent(int threads, int timeout_ms);
 int bk_pool_n_games(const bk_pool *p);
 int bk_pool_n_done(const bk_pool *p);
 int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);

@@ -228,3 +228,35 @@ def test_unsupported_modes_are_refused_not_ignored():
         NativeMCTS(None, evaluator=object(), no_sim=False)
     with pytest.raises(NotImplementedError):
         NativeMCTS(None, evaluator=object(), branch_num=5)
+
+
+@pytest.mark.parametrize("speculate", [0, 8])
+def test_small_collect_cap_never_strands_a_request(speculate):
+    """ADVICE r3 (bk_tree.cpp, add_speculation): with request_tasks > 0 the refill of spilled values was bounded in TASKS
+    (up to 128, or a multiple of 256) but not in ROWS against the collect cap; with the smallest cap a pool allows (82) an
+    expansion with unknown priors (up to 82 rows) plus spilled passengers could outgrow every collect and the game would stall
+    with rollouts outstanding.  Passengers now also stay within the cap: every rollout is played, and the search is the same
+    search as with a roomy cap."""
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    from bokego_amd import selfplay
+    rows = []
+
+    class Ev:
+        inner = selfplay.CallableEvaluator(pol, val)
+        def __call__(self, feats, n_policy):
+            rows.append(len(feats))
+            return self.inner(feats, n_policy)
+    kw = dict(expand_thresh=10, speculate=speculate, speculate_rows=256, request_tasks=64, request_steps=(64, 128, 256))
+    tight = NativeMCTS(Position(), evaluator=Ev(), cap=82, **kw)
+    n_tight = len(rows)
+    roomy = NativeMCTS(Position(), evaluator=selfplay.CallableEvaluator(pol, val), cap=1024, **kw)
+    total = 0
+    for ply in range(8):
+        tight.rollout(600); roomy.rollout(600)
+        total += 600
+        assert tight._pool.info(0)["root_N"] >= 600          # nothing outstanding: no request was stranded
+        assert tight.child_stats() == roomy.child_stats(), ply
+        assert tight.choose().last_move == roomy.choose().last_move
+    assert len(rows) > n_tight and max(rows) <= 82

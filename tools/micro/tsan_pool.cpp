@@ -1,15 +1,43 @@
 // ThreadSanitizer driver of the game pools (bk_tree.cpp: worker team, lanes, emit phase): two pools of 48 games advanced in turn
-// with a fake evaluator, 6 threads each -- no Python, no GPU.   make -C bokego_amd/csrc tsan
+// with a fake evaluator, 6 threads each, then two more pools driven by TWO caller threads at once (the team serves both callers'
+// jobs side by side) and the team's selftests from two threads -- no Python, no GPU.   make -C bokego_amd/csrc tsan
 // Also the gprof driver of the host side: tsan_pool [games per pool] [rollouts] [expand_thresh] [max_turns] [threads]
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/bokego_go.h"
 #include "../../include/bokego_tree.h"
 
 #include <cstdlib>
+constexpr int CAP = 8192;
+// one collect / evaluate (fake, a pure function of the record) / deliver step of a pool; false when every game is finished
+static bool step(bk_pool* pool, long& steps, long& rows) {
+    thread_local std::vector<bk_pos> recs(CAP);
+    thread_local std::vector<float> probs((size_t)CAP * 81), values(CAP);
+    int npol = 0;
+    const int n = bk_pool_collect_pos(pool, recs.data(), CAP, &npol);
+    if (n == 0) return false;
+    for (int r = 0; r < npol; ++r) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+        float sum = 0;
+        for (int k = 0; k < 81; ++k) sum += probs[(size_t)r * 81 + k] = 1.f + (float)((b[k] * 7 + k * 13 + r) % 17);
+        for (int k = 0; k < 81; ++k) probs[(size_t)r * 81 + k] /= sum;
+    }
+    for (int r = 0; r < n; ++r) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+        unsigned h = 0;
+        for (int k = 0; k < 96; ++k) h = h * 31 + b[k];
+        values[r] = (float)(h % 2001) / 1000.f - 1.f;
+    }
+    bk_pool_deliver(pool, probs.data(), values.data());
+    ++steps;
+    rows += n;
+    return true;
+}
+
 int main(int argc, char** argv) {
     bk_search_params prm;
     bk_search_params_default(&prm);
@@ -22,7 +50,6 @@ int main(int argc, char** argv) {
     prm.prune = 1;
     prm.eager_top = 4;
     const int threads = argc > 5 ? atoi(argv[5]) : 6;
-    constexpr int CAP = 8192;
     std::vector<uint64_t> seeds(G);
     bk_pool* pools[2];
     for (int p = 0; p < 2; ++p) {
@@ -30,33 +57,26 @@ int main(int argc, char** argv) {
         pools[p] = bk_pool_create(G, &prm, seeds.data(), threads);
         if (!pools[p]) return 2;
     }
-    std::vector<bk_pos> recs(CAP);
-    std::vector<float> probs((size_t)CAP * 81), values(CAP);
     long steps = 0, rows = 0;
     for (bool busy = true; busy;) {
         busy = false;
-        for (int p = 0; p < 2; ++p) {
-            int npol = 0;
-            const int n = bk_pool_collect_pos(pools[p], recs.data(), CAP, &npol);
-            if (n == 0) continue;
-            busy = true;
-            for (int r = 0; r < npol; ++r) {
-                const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
-                float sum = 0;
-                for (int k = 0; k < 81; ++k) sum += probs[(size_t)r * 81 + k] = 1.f + (float)((b[k] * 7 + k * 13 + r) % 17);
-                for (int k = 0; k < 81; ++k) probs[(size_t)r * 81 + k] /= sum;
-            }
-            for (int r = 0; r < n; ++r) {
-                const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
-                unsigned h = 0;
-                for (int k = 0; k < 96; ++k) h = h * 31 + b[k];
-                values[r] = (float)(h % 2001) / 1000.f - 1.f;
-            }
-            bk_pool_deliver(pools[p], probs.data(), values.data());
-            ++steps;
-            rows += n;
-        }
+        for (int p = 0; p < 2; ++p) busy = step(pools[p], steps, rows) || busy;
     }
+    // two callers at once: each thread drives a pool of its own to the end
+    bk_pool* par[2];
+    long psteps[2] = {0, 0}, prows[2] = {0, 0};
+    for (int p = 0; p < 2; ++p) {
+        for (int g = 0; g < G; ++g) seeds[g] = 30260 + 2 * g + p;
+        par[p] = bk_pool_create(G, &prm, seeds.data(), threads);
+        if (!par[p]) return 2;
+    }
+    {
+        std::thread a([&] { while (step(par[0], psteps[0], prows[0])) {} }), b([&] { while (step(par[1], psteps[1], prows[1])) {} });
+        a.join();
+        b.join();
+    }
+    for (int p = 0; p < 2; ++p) bk_pool_destroy(par[p]);
+    std::printf("tsan_pool: two callers at once: %ld + %ld steps, %ld + %ld rows\n", psteps[0], psteps[1], prows[0], prows[1]);
     long plies = 0;
     for (int p = 0; p < 2; ++p) {
         for (int g = 0; g < G; ++g) {
@@ -67,5 +87,12 @@ int main(int argc, char** argv) {
         bk_pool_destroy(pools[p]);
     }
     std::printf("tsan_pool: %ld steps, %ld rows, %ld plies\n", steps, rows, plies);
-    return bk_team_selftest(4, 20000);
+    int rc = bk_team_selftest(4, 20000);
+    int rc2[2] = {0, 0};
+    {
+        std::thread a([&] { rc2[0] = bk_team_selftest(3, 20000); }), b([&] { rc2[1] = bk_team_selftest(4, 20000); });
+        a.join();
+        b.join();
+    }
+    return rc || rc2[0] || rc2[1] || bk_team_selftest_concurrent(3, 5000);
 }
