@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 5
+BK_ABI_VERSION = 6
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -46,7 +46,9 @@ class Stats(ctypes.Structure):
                 ("last_kernel_ms", ctypes.c_double), ("f16_overflow_fallbacks", ctypes.c_uint64),
                 ("f16_device_overflow", ctypes.c_uint64), ("positions_encoded", ctypes.c_uint64),
                 ("split_launches", ctypes.c_uint64), ("coop_launches", ctypes.c_uint64),
-                ("coop_fallbacks", ctypes.c_uint64)]
+                ("coop_fallbacks", ctypes.c_uint64), ("mean_batch", ctypes.c_double),
+                ("queue_wait_ms_sum", ctypes.c_double), ("queue_wait_count", ctypes.c_uint64),
+                ("host_wait_ms_sum", ctypes.c_double), ("failed_submissions", ctypes.c_uint64)]
 
 
 # every symbol include/bokego_amd.h declares: (restype, argtypes)

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -198,11 +199,22 @@ struct bk_engine {
     Slot slots[BK_MAX_INFLIGHT];
     int64_t next_ticket = 1;
     std::string err;
-    // stats / profiling
+    // stats / profiling.  bk_stats may be called from another thread than the one that submits (a monitor polling it): the
+    // counters are bumped / read with relaxed atomics, the timing-event ring is guarded by ev_m, and bk_stats makes no call
+    // that waits for the device (events are polled with hipEventQuery; the one device-side counter is fetched by a 4-byte
+    // copy on a stream of its own)
     bk_stats_t st{};
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
+    std::mutex ev_m;
+    struct TimedLaunch { hipEvent_t start, stop; double host_ms; bool ticket; };
+    std::vector<TimedLaunch> ev_ring;
     size_t ev_head = 0, ev_pending = 0;
+    hipEvent_t epoch = nullptr;          // recorded at create on an idle device: GPU-side times are measured from it ...
+    std::chrono::steady_clock::time_point epoch_host;   // ... and host-side times from this instant (queue_wait_ms_sum)
+    hipStream_t s_stat = nullptr;        // bk_stats' own stream
+    unsigned int* h_stat = nullptr;      // pinned word the device-side redo counter is copied into
+    // BK_FAULT_SUBMIT=<n> (tests): the n-th HIP call of a ticket submission reports a failure instead of being made
+    int fault_at = 0, fault_seen = 0;
     // device-pointer path, f16x2: a ring of BK_DEV_FLAGS words, one per call (call number % BK_DEV_FLAGS), zeroed in stream
     // order in front of the call's f16x2 kernel, which raises it to the call number on overflow: that is what gates the
     // call's fp32 redo kernel.  One word per call, so calls running concurrently on different caller streams cannot hide
@@ -223,9 +235,16 @@ int fail(bk_engine* e, int code, const std::string& msg) {
     if (e) e->err = msg; else g_create_error = msg;
     return code;
 }
+// test hook (BK_FAULT_SUBMIT, armed by submit_common for the length of one submission): true = this HIP call "fails"
+inline bool inject_fault(bk_engine* e) {
+    if (!e || e->fault_at <= 0 || ++e->fault_seen != e->fault_at) return false;
+    e->fault_at = 0;                                     // one shot
+    return true;
+}
+inline void bump(uint64_t& c, uint64_t v = 1) { __atomic_fetch_add(&c, v, __ATOMIC_RELAXED); }
 #define HIP_TRY(e, call)                                                                       \
     do {                                                                                       \
-        hipError_t _s = (call);                                                                \
+        hipError_t _s = inject_fault(e) ? hipErrorUnknown : (call);                            \
         if (_s != hipSuccess)                                                                  \
             return fail(e, _s == hipErrorOutOfMemory ? BK_ERR_OOM : BK_ERR_HIP,                \
                         std::string(#call) + ": " + hipGetErrorString(_s));                    \
@@ -316,38 +335,35 @@ void pack_trunk16(const bk_trunk_weights& t, std::vector<_Float16>& wfrag, std::
     }
 }
 
-// *out == nullptr: allocate and fill; otherwise refill the buffer that is there (bk_engine_set_weights: every weight array
-// has a size fixed by the architecture)
+// a fresh device buffer holding h; recorded in `fresh` (the caller owns it until the whole set of weights is in place)
 template <typename T>
-int upload(bk_engine* e, const std::vector<T>& h, const T** out) {
-    void* d = const_cast<T*>(*out);
-    if (!d) {
-        HIP_TRY(e, hipMalloc(&d, h.size() * sizeof(T)));
-        e->dev_allocs.push_back(d);
-    }
+int upload(bk_engine* e, const std::vector<T>& h, const T** out, std::vector<void*>& fresh) {
+    void* d = nullptr;
+    HIP_TRY(e, hipMalloc(&d, h.size() * sizeof(T)));
+    fresh.push_back(d);
     HIP_TRY(e, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(d);
     return BK_OK;
 }
 
-int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, double head_scale, double head_shift) {
+int setup_trunk(bk_engine* e, const bk_trunk_weights& t, bk_net_params& np, double head_scale, double head_shift, std::vector<void*>& fresh) {
     std::vector<float> wfrag, bias, hw(128), hb(81);
     pack_trunk(t, wfrag, bias);
     // Conv2dUntiedBias (nnet.py:175-180); for the value net BatchNorm2d(1) is folded in:
     //   bn(h) = (h - mean) * s + beta  with  s = gamma / sqrt(var + eps)
     for (int c = 0; c < 128; ++c) hw[c] = (float)((double)t.head_w[c] * head_scale);
     for (int q = 0; q < 81; ++q) hb[q] = (float)((double)t.head_b[q] * head_scale + head_shift);
-    int rc;
-    if ((rc = upload(e, wfrag, &np.wfrag))) return rc;
-    if ((rc = upload(e, bias, &np.bias))) return rc;
-    if ((rc = upload(e, hw, &np.head_w))) return rc;
-    if ((rc = upload(e, hb, &np.head_b))) return rc;
     std::vector<_Float16> w16;
     std::vector<float> b16;
     pack_trunk16(t, w16, b16, np.cscale16);
     np.inv_sa16 = 1.f / kSa16;
-    if ((rc = upload(e, w16, &np.wfrag16))) return rc;
-    if ((rc = upload(e, b16, &np.bias16))) return rc;
+    int rc;
+    if ((rc = upload(e, wfrag, &np.wfrag, fresh))) return rc;
+    if ((rc = upload(e, bias, &np.bias, fresh))) return rc;
+    if ((rc = upload(e, hw, &np.head_w, fresh))) return rc;
+    if ((rc = upload(e, hb, &np.head_b, fresh))) return rc;
+    if ((rc = upload(e, w16, &np.wfrag16, fresh))) return rc;
+    if ((rc = upload(e, b16, &np.bias16, fresh))) return rc;
     return BK_OK;
 }
 
@@ -362,31 +378,60 @@ bool weights_ok(const bk_policy_weights* policy, const bk_value_weights* value) 
     return true;
 }
 
-// fold BatchNorm, pack and upload the weights of the nets given (nullptr: that net is left alone); device buffers are
-// allocated on first use and refilled afterwards
+// every device buffer a net's parameter block points at
+std::vector<const void*> net_buffers(const bk_net_params& np) {
+    return {np.wfrag, np.bias, np.head_w, np.head_b, np.lin1_wt, np.lin1_b, np.lin2_w, np.wfrag16, np.bias16};
+}
+
+// Fold BatchNorm, pack and upload the weights of the nets given (nullptr: that net is left alone).  All or nothing: the new
+// weights go into FRESH device buffers, and only when every one of them is in place do the engine's parameter blocks switch
+// over (the old buffers are freed); on any failure the fresh buffers are freed and the engine is exactly as before -- never
+// a mixture of old and new weights.  The caller has made sure nothing on the device still reads the old buffers.
 int load_weights(bk_engine* e, const bk_policy_weights* policy, const bk_value_weights* value) {
-    int rc;
-    if (policy) {
-        if ((rc = setup_trunk(e, policy->trunk, e->net[0], 1.0, 0.0))) return rc;
-    }
-    if (value) {
-        const bk_value_head_weights& h = value->head;
-        const double s = (double)h.bn_w[0] / std::sqrt((double)h.bn_var[0] + kBnEps);
-        const double shift = (double)h.bn_b[0] - (double)h.bn_mean[0] * s;
-        if ((rc = setup_trunk(e, value->trunk, e->net[1], s, shift))) return rc;
-        // lin1 (64,81) + BatchNorm1d(64) folded, stored transposed [81][64] for coalesced reads
-        std::vector<float> w1t(81 * 64), b1(64), w2(64);
-        for (int j = 0; j < 64; ++j) {
-            const double sj = (double)h.lin_bn_w[j] / std::sqrt((double)h.lin_bn_var[j] + kBnEps);
-            for (int q = 0; q < 81; ++q) w1t[q * 64 + j] = (float)((double)h.lin1_w[j * 81 + q] * sj);
-            b1[j] = (float)(((double)h.lin1_b[j] - (double)h.lin_bn_mean[j]) * sj + (double)h.lin_bn_b[j]);
-            w2[j] = h.lin2_w[j];
+    bk_net_params np[2] = {e->net[0], e->net[1]};
+    std::vector<void*> fresh;
+    auto build = [&]() -> int {
+        int rc;
+        if (policy) {
+            np[0] = bk_net_params{};
+            if ((rc = setup_trunk(e, policy->trunk, np[0], 1.0, 0.0, fresh))) return rc;
         }
-        if ((rc = upload(e, w1t, &e->net[1].lin1_wt))) return rc;
-        if ((rc = upload(e, b1, &e->net[1].lin1_b))) return rc;
-        if ((rc = upload(e, w2, &e->net[1].lin2_w))) return rc;
-        e->net[1].lin2_b = h.lin2_b[0];
+        if (value) {
+            np[1] = bk_net_params{};
+            const bk_value_head_weights& h = value->head;
+            const double s = (double)h.bn_w[0] / std::sqrt((double)h.bn_var[0] + kBnEps);
+            const double shift = (double)h.bn_b[0] - (double)h.bn_mean[0] * s;
+            if ((rc = setup_trunk(e, value->trunk, np[1], s, shift, fresh))) return rc;
+            // lin1 (64,81) + BatchNorm1d(64) folded, stored transposed [81][64] for coalesced reads
+            std::vector<float> w1t(81 * 64), b1(64), w2(64);
+            for (int j = 0; j < 64; ++j) {
+                const double sj = (double)h.lin_bn_w[j] / std::sqrt((double)h.lin_bn_var[j] + kBnEps);
+                for (int q = 0; q < 81; ++q) w1t[q * 64 + j] = (float)((double)h.lin1_w[j * 81 + q] * sj);
+                b1[j] = (float)(((double)h.lin1_b[j] - (double)h.lin_bn_mean[j]) * sj + (double)h.lin_bn_b[j]);
+                w2[j] = h.lin2_w[j];
+            }
+            if ((rc = upload(e, w1t, &np[1].lin1_wt, fresh))) return rc;
+            if ((rc = upload(e, b1, &np[1].lin1_b, fresh))) return rc;
+            if ((rc = upload(e, w2, &np[1].lin2_w, fresh))) return rc;
+            np[1].lin2_b = h.lin2_b[0];
+        }
+        return BK_OK;
+    };
+    if (const int rc = build()) {
+        for (void* d : fresh) (void)hipFree(d);
+        return rc;
     }
+    for (int i = 0; i < 2; ++i) {
+        if (!(i == 0 ? (const void*)policy : (const void*)value)) continue;
+        for (const void* old : net_buffers(e->net[i])) {
+            if (!old) continue;
+            auto it = std::find(e->dev_allocs.begin(), e->dev_allocs.end(), const_cast<void*>(old));
+            if (it != e->dev_allocs.end()) e->dev_allocs.erase(it);
+            (void)hipFree(const_cast<void*>(old));
+        }
+        e->net[i] = np[i];
+    }
+    e->dev_allocs.insert(e->dev_allocs.end(), fresh.begin(), fresh.end());
     return BK_OK;
 }
 
@@ -438,16 +483,32 @@ int check_want(bk_engine* e, int B, int n_policy, int want) {
     return BK_OK;
 }
 
-void drain_events(bk_engine* e) {
-    // fold finished (start, stop) pairs into the stats; called with the stream idle
+// fold the (start, stop) pairs of launches that have FINISHED into the stats, oldest first; stops at the first one still in
+// flight (hipEventQuery: never waits).  Caller holds ev_m.  wait_oldest: the ring is full -- wait for its oldest entry.
+void drain_events(bk_engine* e, bool wait_oldest = false) {
     const size_t n = e->ev_ring.size();
     while (e->ev_pending) {
         const size_t i = (e->ev_head + n - e->ev_pending) % n;
+        bk_engine::TimedLaunch& t = e->ev_ring[i];
+        if (wait_oldest) {
+            (void)hipEventSynchronize(t.stop);
+            wait_oldest = false;
+        } else if (hipEventQuery(t.stop) != hipSuccess) {
+            (void)hipGetLastError();     // hipErrorNotReady is not an error
+            break;
+        }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e->ev_ring[i].first, e->ev_ring[i].second) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
             e->st.kernel_ms_sum += ms;
-            e->st.kernel_ms_count += 1;
+            bump(e->st.kernel_ms_count);
             e->st.last_kernel_ms = ms;
+        }
+        // how long the request sat between the host handing it over and the GPU starting its first kernel: GPU-side start
+        // (measured from the epoch event) minus host-side enqueue time (measured from the instant the epoch was recorded)
+        float since = 0.f;
+        if (t.ticket && e->epoch && hipEventElapsedTime(&since, e->epoch, t.start) == hipSuccess) {
+            e->st.queue_wait_ms_sum += std::max(0.0, (double)since - t.host_ms);
+            bump(e->st.queue_wait_count);
         }
         --e->ev_pending;
     }
@@ -519,14 +580,24 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     bool timed = false;
     size_t slot = 0;
     if (e->profiling) {
-        if (e->ev_pending == e->ev_ring.size()) {  // ring full: wait for the stream and fold
-            HIP_TRY(e, hipStreamSynchronize(stream));
-            drain_events(e);
-        }
+        std::lock_guard<std::mutex> g(e->ev_m);
+        drain_events(e);
+        if (e->ev_pending == e->ev_ring.size()) drain_events(e, /*wait_oldest=*/true);   // ring full
         slot = e->ev_head;
-        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].first, stream));
+        e->ev_ring[slot].host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->epoch_host).count();
+        e->ev_ring[slot].ticket = stream == e->stream && lo == 0;
+        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].start, stream));
+        // the slot is taken now (its stop event is recorded below); until then a concurrent bk_stats must not fold it
         timed = true;
     }
+    auto close_timing = [&]() -> int {
+        if (!timed) return BK_OK;
+        std::lock_guard<std::mutex> g(e->ev_m);
+        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].stop, stream));
+        e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
+        ++e->ev_pending;
+        return BK_OK;
+    };
     a.overflow = d_flag;
     a.overflow_tag = tag;
     a.gate_count = 1;
@@ -553,14 +624,10 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         a.coop_tag = 1;
         a.coop_fault = getenv("BK_COOP_FAULT") != nullptr;
         HIP_TRY(e, bk_launch_leaf_eval_coop(a, slices, stream));
-        e->st.coop_launches += 1;
-        if (timed) {
-            HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
-            e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
-            ++e->ev_pending;
-        }
-        e->st.evals += (uint64_t)B;
-        e->st.batches += 1;
+        bump(e->st.coop_launches);
+        if (const int trc = close_timing()) return trc;
+        bump(e->st.evals, (uint64_t)B);
+        bump(e->st.batches);
         if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
         return BK_OK;
     }
@@ -576,17 +643,13 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         t.off_p = a.off_p + 3 * head_p;
         t.off_v = a.off_v + 3 * head_v;
         HIP_TRY(e, launch(t, tail_nb));
-        e->st.split_launches += 1;
+        bump(e->st.split_launches);
     } else {
         HIP_TRY(e, launch(a, nb1));
     }
-    if (timed) {
-        HIP_TRY(e, hipEventRecord(e->ev_ring[slot].second, stream));
-        e->ev_head = (e->ev_head + 1) % e->ev_ring.size();
-        ++e->ev_pending;
-    }
-    e->st.evals += (uint64_t)(hi - lo);
-    e->st.batches += lo == 0 ? 1 : 0;
+    if (const int trc = close_timing()) return trc;
+    bump(e->st.evals, (uint64_t)(hi - lo));
+    bump(e->st.batches, lo == 0 ? 1 : 0);
     if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
     return BK_OK;
 }
@@ -670,9 +733,17 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
         if ((rc = alloc_slot(e, s))) return bail(rc);
     e->ev_ring.resize(512);
     for (auto& p : e->ev_ring) {
-        TRY_CREATE(hipEventCreate(&p.first));
-        TRY_CREATE(hipEventCreate(&p.second));
+        TRY_CREATE(hipEventCreate(&p.start));
+        TRY_CREATE(hipEventCreate(&p.stop));
     }
+    TRY_CREATE(hipStreamCreateWithFlags(&e->s_stat, hipStreamNonBlocking));
+    TRY_CREATE(hipHostMalloc((void**)&e->h_stat, 64, hipHostMallocDefault));
+    e->h_stat[0] = 0;
+    TRY_CREATE(hipEventCreate(&e->epoch));
+    TRY_CREATE(hipStreamSynchronize(e->stream));          // idle: the epoch event completes at once
+    TRY_CREATE(hipEventRecord(e->epoch, e->stream));
+    e->epoch_host = std::chrono::steady_clock::now();
+    TRY_CREATE(hipEventSynchronize(e->epoch));
 #undef TRY_CREATE
     *out = e;
     return BK_OK;
@@ -684,10 +755,14 @@ int bk_engine_destroy(bk_engine* e) {
     for (hipStream_t st : {e->s_in, e->stream, e->s_out})
         if (st) (void)hipStreamSynchronize(st);
     for (auto& s : e->slots) free_slot(s);
+    if (e->s_stat) (void)hipStreamSynchronize(e->s_stat);
     for (auto& p : e->ev_ring) {
-        if (p.first) (void)hipEventDestroy(p.first);
-        if (p.second) (void)hipEventDestroy(p.second);
+        if (p.start) (void)hipEventDestroy(p.start);
+        if (p.stop) (void)hipEventDestroy(p.stop);
     }
+    if (e->epoch) (void)hipEventDestroy(e->epoch);
+    if (e->h_stat) (void)hipHostFree(e->h_stat);
+    if (e->s_stat) (void)hipStreamDestroy(e->s_stat);
     for (void* d : e->dev_allocs) (void)hipFree(d);
     for (hipStream_t st : {e->s_in, e->stream, e->s_out})
         if (st) (void)hipStreamDestroy(st);
@@ -705,13 +780,36 @@ int bk_engine_set_weights(bk_engine* e, const bk_policy_weights* policy, const b
     for (auto& s : e->slots)
         if (s.busy) return fail(e, BK_ERR_ARG, "tickets outstanding: bk_wait for them before replacing the weights");
     HIP_TRY(e, hipSetDevice(e->device));
-    for (hipStream_t st : {e->s_in, e->stream, e->s_out}) HIP_TRY(e, hipStreamSynchronize(st));
-    return load_weights(e, policy, value);      // blocking copies into the buffers the kernels already point at
+    // bk_eval_device* launches may still run on caller streams (a non-blocking torch stream is not covered by the implicit
+    // synchronisation of a null-stream copy): nothing on the device may read the old buffers when they are freed
+    HIP_TRY(e, hipDeviceSynchronize());
+    return load_weights(e, policy, value);      // all or nothing: fresh buffers, parameter blocks switched at the end
 }
 
 namespace {
 
 constexpr int kSrcPositions = 2;  // beside BK_FEATS_F32 (0) / BK_FEATS_U8 (1)
+
+int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B, int n_policy, int want, float* logits,
+                    float* probs, float* values);
+
+// A submission failed part-way (a HIP call after the first enqueue returned an error): copies and kernels already queued
+// still use the slot's staging and output blocks, and the slot is about to be handed to the next request.  Wait for
+// everything the engine has queued, put the slot's flag words (device and pinned) back to zero and leave it free with
+// nothing in flight; the engine's error text stays that of the failed call.  Later requests then run as usual.
+void abort_submission(bk_engine* e, Slot* s) {
+    const std::string why = e->err;
+    for (hipStream_t st : {e->s_in, e->stream, e->s_out})
+        if (st) (void)hipStreamSynchronize(st);
+    if (s->d_out) (void)hipMemset(s->d_out, 0, 2 * sizeof(unsigned int));
+    if (s->h_out) std::memset(s->h_out, 0, 2 * sizeof(unsigned int));
+    (void)hipGetLastError();
+    s->flag_dirty = false;
+    s->direct = false;
+    s->busy = false;
+    bump(e->st.failed_submissions);
+    e->err = why;
+}
 
 // common body of the ticket entry points; src_kind: BK_FEATS_F32, BK_FEATS_U8 or kSrcPositions
 int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_policy, int want, float* logits,
@@ -727,6 +825,19 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         if (!c.busy) { s = &c; break; }
     if (!s) return fail(e, BK_ERR_ARG, "more than BK_MAX_INFLIGHT tickets outstanding");
     HIP_TRY(e, hipSetDevice(e->device));
+    if (const char* f = getenv("BK_FAULT_SUBMIT")) {      // tests: the n-th HIP call of this submission fails
+        e->fault_at = atoi(f);
+        e->fault_seen = 0;
+    }
+    const int64_t t = submit_body(e, s, src, src_kind, B, n_policy, want, logits, probs, values);
+    e->fault_at = 0;
+    if (t < 0) abort_submission(e, s);
+    return t;
+}
+
+int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B, int n_policy, int want, float* logits,
+                    float* probs, float* values) {
+    int rc = BK_OK;
     const size_t bytes = (size_t)B * (src_kind == kSrcPositions ? (size_t)BK_POS_BYTES : src_kind == BK_FEATS_U8 ? 2187 : 2187 * 4);
     const int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
     // small requests (the single-tree genmove regime) have nothing to overlap: everything goes on the compute
@@ -792,7 +903,7 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         static const bool enc_overlap = getenv("BK_ENCODE_OVERLAP") != nullptr;
         if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
             HIP_TRY(e, bk_launch_encode(direct ? s->h_in_dev : s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
-            e->st.positions_encoded += (uint64_t)B;
+            bump(e->st.positions_encoded, (uint64_t)B);
         }
         if (chained && !two_part) {
             HIP_TRY(e, hipEventRecord(s->in_ready, e->s_in));
@@ -800,7 +911,7 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         }
         if (src_kind == kSrcPositions && !enc_overlap && chained) {
             HIP_TRY(e, bk_launch_encode(s->d_pos, B, static_cast<uint8_t*>(s->d_in), e->stream));
-            e->st.positions_encoded += (uint64_t)B;
+            bump(e->st.positions_encoded, (uint64_t)B);
         }
         // output block of this request
         s->off_values = 64;
@@ -885,7 +996,7 @@ int bk_encode_positions(bk_engine* e, const void* positions, int B, uint8_t* pla
     HIP_TRY(e, hipMemcpyAsync(h_planes, s->d_in, (size_t)B * 2187, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     std::memcpy(planes, h_planes, (size_t)B * 2187);
-    e->st.positions_encoded += (uint64_t)B;
+    bump(e->st.positions_encoded, (uint64_t)B);
     return BK_OK;
 }
 
@@ -894,7 +1005,11 @@ int bk_wait(bk_engine* e, int64_t ticket) {
     RoctxRange range("bk_wait");
     for (auto& s : e->slots) {
         if (!s.busy || s.ticket != ticket) continue;
-        HIP_TRY(e, hipEventSynchronize(s.done));
+        {
+            const auto w0 = std::chrono::steady_clock::now();
+            HIP_TRY(e, hipEventSynchronize(s.done));
+            e->st.host_wait_ms_sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        }
         const unsigned int* hf = reinterpret_cast<const unsigned int*>(s.h_out);
         if (s.B > 0 && (hf[0] || hf[1])) {
             // word 0: the f16x2 kernel clamped an activation -- redo this request on the exact fp32 kernel;
@@ -903,10 +1018,10 @@ int bk_wait(bk_engine* e, int64_t ticket) {
             // Cooperative requests that were queued behind the failed one ran before this memset: they saw the poison
             // word, raised their own word 1 and are redone here as well when their turn to be waited for comes)
             if (hf[1]) {
-                e->st.coop_fallbacks += 1;
+                bump(e->st.coop_fallbacks);
                 HIP_TRY(e, hipMemsetAsync(e->d_coop_sync, 0, (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int), e->stream));  // counters + poison word
             } else {
-                e->st.f16_overflow_fallbacks += 1;
+                bump(e->st.f16_overflow_fallbacks);
             }
             s.flag_dirty = true;
             int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, reinterpret_cast<float*>(s.d_out + s.off_logits),
@@ -991,21 +1106,28 @@ int bk_engine_synchronize(bk_engine* e) {
 }
 
 int bk_stats(bk_engine* e, bk_stats_t* out) {
+    // No call in here waits for the device's other streams (it used to be a hipDeviceSynchronize: a monitor polling the
+    // counters stalled every stream of every engine on the card).  Timing events that have completed are folded, the
+    // others stay pending; the one counter that lives in device memory is fetched by a 4-byte copy on bk_stats' own
+    // non-blocking stream -- a snapshot: calls still in flight on caller streams are counted once they have run.
     if (!e || !out) return BK_ERR_ARG;
-    if (e->ev_pending) {
-        // events may sit on a caller-provided stream: a device sync covers both cases
-        HIP_TRY(e, hipSetDevice(e->device));
-        HIP_TRY(e, hipDeviceSynchronize());
-        drain_events(e);
+    {
+        std::lock_guard<std::mutex> g(e->ev_m);
+        if (e->ev_pending) drain_events(e);
+        if (e->d_dev_flag && e->dev_seq && e->s_stat && e->h_stat) {  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
+            HIP_TRY(e, hipSetDevice(e->device));
+            HIP_TRY(e, hipMemcpyAsync(e->h_stat, e->d_dev_flag + BK_DEV_FLAGS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->s_stat));
+            HIP_TRY(e, hipStreamSynchronize(e->s_stat));
+            e->st.f16_device_overflow = e->h_stat[0];
+        }
+        bk_stats_t snap;
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&e->st);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&snap);
+        static_assert(sizeof(bk_stats_t) % 8 == 0, "bk_stats_t is a sequence of 8-byte fields");
+        for (size_t i = 0; i < sizeof(bk_stats_t) / 8; ++i) dst[i] = __atomic_load_n(src + i, __ATOMIC_RELAXED);
+        snap.mean_batch = snap.batches ? (double)snap.evals / (double)snap.batches : 0.0;
+        *out = snap;
     }
-    if (e->d_dev_flag && e->dev_seq) {  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
-        unsigned int f = 0;
-        HIP_TRY(e, hipSetDevice(e->device));
-        HIP_TRY(e, hipDeviceSynchronize());  // the calls may sit on any caller stream
-        HIP_TRY(e, hipMemcpy(&f, e->d_dev_flag + BK_DEV_FLAGS, sizeof(f), hipMemcpyDeviceToHost));
-        e->st.f16_device_overflow = f;
-    }
-    *out = e->st;
     return BK_OK;
 }
 
@@ -1044,6 +1166,15 @@ int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* 
     if (executed_mfma_flop) *executed_mfma_flop = exe;
     if (algorithmic_flop) *algorithmic_flop = alg;
     if (n_launches) *n_launches = launches;
+    return BK_OK;
+}
+
+// test hook (not part of include/bokego_amd.h; tests/test_gpu_engine_hygiene.py): the n-th HIP call the engine makes from now
+// on reports a failure instead of being made, once.  BK_FAULT_SUBMIT arms the same counter for one ticket submission.
+int bk_debug_fail_nth_hip_call(bk_engine* e, int n) {
+    if (!e) return BK_ERR_ARG;
+    e->fault_at = n;
+    e->fault_seen = 0;
     return BK_OK;
 }
 

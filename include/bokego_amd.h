@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 5
+#define BK_ABI_VERSION 6
 
 typedef enum bk_status {
     BK_OK = 0,
@@ -93,6 +93,12 @@ typedef struct bk_stats_t {
     uint64_t split_launches;         /* evaluations run as whole rounds of 3-board workgroups + a shorter tail launch */
     uint64_t coop_launches;          /* small fp32 batches run with 2..12 CUs per board (cooperative launch) */
     uint64_t coop_fallbacks;         /* ... of which redone by the one-CU form because a workgroup gave up waiting for its peers */
+    /* ABI 6 (metrics row: "mean batch, queue wait") */
+    double mean_batch;               /* evals / batches */
+    double queue_wait_ms_sum;        /* profiling on, ticket path: per request, the time between the host handing it over and the GPU starting its first kernel */
+    uint64_t queue_wait_count;       /* ... number of requests in that sum */
+    double host_wait_ms_sum;         /* time the caller spent blocked inside bk_wait */
+    uint64_t failed_submissions;     /* bk_submit* calls that failed after queueing work: drained, slot left clean (BK_ERR_HIP / BK_ERR_OOM returned) */
 } bk_stats_t;
 
 int bk_abi_version(void);

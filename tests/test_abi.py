@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, f), f"{f} declared in include/bokego_amd.h but not exported"
         assert f in _lib.SYMBOLS, f"{f} has no ctypes prototype in bokego_amd/_lib.py"
     assert set(_lib.SYMBOLS) == set(fns)
-    assert lib.bk_abi_version() == 5
+    assert lib.bk_abi_version() == 6
 
 
 def test_plan_flops_counts_the_tile_tables(lib):
@@ -61,7 +61,7 @@ def test_struct_layout_matches_header():
     # 7*6 + 2 pointers in the trunk, +12 in the value head (include/bokego_amd.h)
     assert ctypes.sizeof(_lib.TrunkWeights) == 44 * 8
     assert ctypes.sizeof(_lib.ValueWeights) == 56 * 8
-    assert ctypes.sizeof(_lib.Stats) == 96
+    assert ctypes.sizeof(_lib.Stats) == 96 + 5 * 8       # ABI 6: mean_batch, queue_wait_ms_sum, queue_wait_count, host_wait_ms_sum, failed_submissions
 
 
 def test_create_argument_errors(lib):
