@@ -211,15 +211,20 @@ struct bk_engine {
     size_t ev_head = 0, ev_pending = 0;
     hipEvent_t epoch = nullptr;          // recorded at create on an idle device: GPU-side times are measured from it ...
     std::chrono::steady_clock::time_point epoch_host;   // ... and host-side times from this instant (queue_wait_ms_sum)
-    hipStream_t s_stat = nullptr;        // bk_stats' own stream
-    unsigned int* h_stat = nullptr;      // pinned word the device-side redo counter is copied into
+    // device-pointer path, f16x2: which calls were redone in fp32.  The gated redo kernel of call number N stores N into word
+    // N % BK_DEV_FLAGS of this PINNED block (a plain system-scope store by one thread; no atomics on host memory), the host
+    // counts the words that changed -- when bk_stats is asked, and before a word is reused 256 calls later -- without any
+    // call into the device.  (A copy from device memory, even on a stream of its own, queues on the copy engine behind the
+    // tickets' copies, which wait for their kernels: 32 ms for a counter.)
+    unsigned int* h_redo = nullptr;
+    unsigned int* h_redo_dev = nullptr;  // the same block as the GPU addresses it
+    unsigned int redo_seen[BK_DEV_FLAGS] = {};
     // BK_FAULT_SUBMIT=<n> (tests): the n-th HIP call of a ticket submission reports a failure instead of being made
     int fault_at = 0, fault_seen = 0;
     // device-pointer path, f16x2: a ring of BK_DEV_FLAGS words, one per call (call number % BK_DEV_FLAGS), zeroed in stream
     // order in front of the call's f16x2 kernel, which raises it to the call number on overflow: that is what gates the
     // call's fp32 redo kernel.  One word per call, so calls running concurrently on different caller streams cannot hide
     // each other's overflow (with ONE shared word, atomicMax(flag, N) was a no-op once call N+1 had raised it: ADVICE r2).
-    // [BK_DEV_FLAGS] = number of calls redone.
     unsigned int* d_dev_flag = nullptr;
     unsigned int dev_seq = 0;
     // cooperative small-batch launches (ticket path on the compute stream only: one exchange buffer): the exchange buffer
@@ -483,6 +488,16 @@ int check_want(bk_engine* e, int B, int n_policy, int want) {
     return BK_OK;
 }
 
+// a redo word that changed since it was last looked at = one more device-path call redone in fp32 (called by the submitting
+// thread, or by bk_stats; a late store by a call still in flight when its word is reused can be missed: a statistic)
+void fold_redo(bk_engine* e, unsigned int slot) {
+    const unsigned int v = __atomic_load_n(e->h_redo + slot, __ATOMIC_RELAXED);
+    if (v != e->redo_seen[slot]) {
+        e->redo_seen[slot] = v;
+        bump(e->st.f16_device_overflow);
+    }
+}
+
 // fold the (start, stop) pairs of launches that have FINISHED into the stats, oldest first; stops at the first one still in
 // flight (hipEventQuery: never waits).  Caller holds ev_m.  wait_oldest: the ring is full -- wait for its oldest entry.
 void drain_events(bk_engine* e, bool wait_oldest = false) {
@@ -610,7 +625,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         r.overflow = nullptr;
         r.gate = d_flag;
         r.gate_tag = tag;
-        r.gate_counter = e->d_dev_flag + BK_DEV_FLAGS;
+        r.gate_counter = e->h_redo_dev + tag % BK_DEV_FLAGS;
         return bk_launch_leaf_eval(r, nb, stream);
     };
     // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
@@ -718,9 +733,12 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     TRY_CREATE(hipMalloc((void**)&e->d_stamps, (size_t)BK_STAMP_BLOCKS * 4 * 32 * 8));
     e->dev_allocs.push_back(e->d_stamps);
 #endif
-    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, (BK_DEV_FLAGS + 1) * sizeof(unsigned int)));
+    TRY_CREATE(hipMalloc((void**)&e->d_dev_flag, BK_DEV_FLAGS * sizeof(unsigned int)));
     e->dev_allocs.push_back(e->d_dev_flag);
-    TRY_CREATE(hipMemset(e->d_dev_flag, 0, (BK_DEV_FLAGS + 1) * sizeof(unsigned int)));
+    TRY_CREATE(hipMemset(e->d_dev_flag, 0, BK_DEV_FLAGS * sizeof(unsigned int)));
+    TRY_CREATE(hipHostMalloc((void**)&e->h_redo, BK_DEV_FLAGS * sizeof(unsigned int), hipHostMallocDefault));
+    std::memset(e->h_redo, 0, BK_DEV_FLAGS * sizeof(unsigned int));
+    TRY_CREATE(hipHostGetDevicePointer((void**)&e->h_redo_dev, e->h_redo, 0));
     {
         const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
@@ -736,9 +754,6 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
         TRY_CREATE(hipEventCreate(&p.start));
         TRY_CREATE(hipEventCreate(&p.stop));
     }
-    TRY_CREATE(hipStreamCreateWithFlags(&e->s_stat, hipStreamNonBlocking));
-    TRY_CREATE(hipHostMalloc((void**)&e->h_stat, 64, hipHostMallocDefault));
-    e->h_stat[0] = 0;
     TRY_CREATE(hipEventCreate(&e->epoch));
     TRY_CREATE(hipStreamSynchronize(e->stream));          // idle: the epoch event completes at once
     TRY_CREATE(hipEventRecord(e->epoch, e->stream));
@@ -755,14 +770,12 @@ int bk_engine_destroy(bk_engine* e) {
     for (hipStream_t st : {e->s_in, e->stream, e->s_out})
         if (st) (void)hipStreamSynchronize(st);
     for (auto& s : e->slots) free_slot(s);
-    if (e->s_stat) (void)hipStreamSynchronize(e->s_stat);
     for (auto& p : e->ev_ring) {
         if (p.start) (void)hipEventDestroy(p.start);
         if (p.stop) (void)hipEventDestroy(p.stop);
     }
     if (e->epoch) (void)hipEventDestroy(e->epoch);
-    if (e->h_stat) (void)hipHostFree(e->h_stat);
-    if (e->s_stat) (void)hipStreamDestroy(e->s_stat);
+    if (e->h_redo) (void)hipHostFree(e->h_redo);
     for (void* d : e->dev_allocs) (void)hipFree(d);
     for (hipStream_t st : {e->s_in, e->stream, e->s_out})
         if (st) (void)hipStreamDestroy(st);
@@ -1078,6 +1091,10 @@ int bk_eval_device_prefix(bk_engine* e, const void* d_feats, int feats_dtype, in
     // torch.cuda.current_stream() is unless the caller switched streams.
     if (++e->dev_seq == 0) e->dev_seq = 1;  // 0 is the flag's reset value
     unsigned int* flag = e->d_dev_flag + e->dev_seq % BK_DEV_FLAGS;   // this call's own word (see d_dev_flag)
+    if (e->precision == BK_PRECISION_F16X2) {                         // ... and its redo word: count what the call 256 ago left there
+        std::lock_guard<std::mutex> g(e->ev_m);
+        fold_redo(e, e->dev_seq % BK_DEV_FLAGS);
+    }
     if (e->precision == BK_PRECISION_F16X2 && B > 0) HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(unsigned int), static_cast<hipStream_t>(stream)));
     return enqueue(e, d_feats, feats_dtype, B, n_policy, want, d_logits, d_probs, d_values,
                    static_cast<hipStream_t>(stream), e->precision, flag, e->dev_seq, true);
@@ -1108,18 +1125,14 @@ int bk_engine_synchronize(bk_engine* e) {
 int bk_stats(bk_engine* e, bk_stats_t* out) {
     // No call in here waits for the device's other streams (it used to be a hipDeviceSynchronize: a monitor polling the
     // counters stalled every stream of every engine on the card).  Timing events that have completed are folded, the
-    // others stay pending; the one counter that lives in device memory is fetched by a 4-byte copy on bk_stats' own
-    // non-blocking stream -- a snapshot: calls still in flight on caller streams are counted once they have run.
+    // others stay pending; the redone device-path calls are read out of pinned memory (h_redo) -- a snapshot: calls still in
+    // flight on caller streams are counted once they have run.
     if (!e || !out) return BK_ERR_ARG;
     {
         std::lock_guard<std::mutex> g(e->ev_m);
         if (e->ev_pending) drain_events(e);
-        if (e->d_dev_flag && e->dev_seq && e->s_stat && e->h_stat) {  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
-            HIP_TRY(e, hipSetDevice(e->device));
-            HIP_TRY(e, hipMemcpyAsync(e->h_stat, e->d_dev_flag + BK_DEV_FLAGS, sizeof(unsigned int), hipMemcpyDeviceToHost, e->s_stat));
-            HIP_TRY(e, hipStreamSynchronize(e->s_stat));
-            e->st.f16_device_overflow = e->h_stat[0];
-        }
+        if (e->h_redo && e->dev_seq)                  // bk_eval_device* calls whose f16x2 kernel overflowed and were redone in fp32
+            for (unsigned int i = 0; i < BK_DEV_FLAGS; ++i) fold_redo(e, i);
         bk_stats_t snap;
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&e->st);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&snap);

@@ -57,7 +57,7 @@ struct bk_eval_args {
     // exact-fp32 kernel launched as the REDO of an f16x2 call on the device-pointer path: every workgroup returns at
     // once unless gate[0] == gate_tag (the f16x2 kernel of the same call raised the call's flag word)
     unsigned int* gate;
-    unsigned int* gate_counter;  // counts redone calls
+    unsigned int* gate_counter;  // the call's "redone" word (pinned host memory): receives gate_tag
     unsigned int gate_tag;
     int gate_count;              // this launch is the call's last one: it does the counting (a call may be two launches)
     // cooperative (cout-split) launches for small batches, bk_kernels.hip: exchange buffer [BK_COOP_MAX_TASKS][2][81][128]

@@ -38,6 +38,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// pointers that are LDS pointers by TYPE (32 bits, ds_* instructions): pointers kept in arrays across layers, or in a struct, are
+// beyond what the compiler's address-space inference follows -- it falls back to generic (flat_*) accesses, which wait on both
+// counters and halved the kernel's rate when that happened during development
+typedef __attribute__((address_space(3))) const char lds_cchar;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+
 
 #ifndef BK_EXP
 #define BK_EXP 0
@@ -88,13 +94,7 @@ struct Geo {
     static_assert(L0_BYTES <= L3_BYTES, "the layer-0 input lives inside the activation region");
         // 8 waves per workgroup = two per SIMD: while one wave issues its loads and waits, the other's MFMA keeps the matrix
     // pipe busy (measured on the earlier 32-row-tile loop: 65.06 cycles per 64-cycle MFMA with one wave per SIMD, +1.1 % with two)
-#if BK_EXP & 4
-    // timing experiment (make exp EXP=4, wrong results): a THIRD wave per SIMD that works on the packed-FP32 vector ALU beside the
-    // two MFMA waves; 3-board workgroups only
-    static constexpr int NW = NB == 3 ? 12 : 8;
-#else
     static constexpr int NW = 8;
-#endif
     static constexpr int THREADS = 64 * NW;
     static constexpr int DUMMY_FLOATS = 256;        // sink for the padding rows' stores (one shared record: never read)
     static constexpr int HS_FLOATS = NB * 96;
@@ -146,16 +146,13 @@ struct Tiles {
     // (1 board: 81 points in 6 tiles, too few per edge class to fill a tile: every tile runs every tap)
     static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 6;
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
-#if BK_EXP & 4
-    static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 7 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;   // tile 7: the vector waves' share
-#else
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
-#endif
     static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
+    static constexpr bool DB2 = NB != 3;                // second chain: double-buffered fragments too (conv_layer) where registers allow
 };
 struct TileRow { int b, y, x; bool valid; };
 template <int NB>
-__device__ __forceinline__ TileRow tile_row(int wm, int rt, int p16) {
+constexpr TileRow tile_row(int wm, int rt, int p16) {
     TileRow r{0, 4, 0, true};
     if constexpr (NB == 1) {
         const int i = rt * 16 + p16;
@@ -188,41 +185,76 @@ __device__ __forceinline__ TileRow tile_row(int wm, int rt, int p16) {
     if (!r.valid) { r.b = 0; r.y = 4; r.x = 0; }   // padding rows compute from a valid address; stored to the dummy record
     return r;
 }
+// the same as a table in device memory, built at compile time: per (position group, tile, row of the tile) the LDS byte offsets
+// of the position's tap-(0,0) neighbour in the layer-0 layout and in the 128-channel layout (bit 0 of the latter: a real board
+// point, not a padding row).  The kernels read their eight-odd entries instead of decoding (divisions) in registers.
+template <int NB>
+struct RowTable {
+    static constexpr int N = Tiles<NB>::WM * Tiles<NB>::RT * 16;
+    int a0[N], a3v[N];
+};
+template <int NB>
+constexpr RowTable<NB> make_row_table() {
+    RowTable<NB> t{};
+    for (int wm = 0; wm < Tiles<NB>::WM; ++wm)
+        for (int rt = 0; rt < Tiles<NB>::RT; ++rt)
+            for (int p = 0; p < 16; ++p) {
+                const TileRow r = tile_row<NB>(wm, rt, p);
+                const int i = (wm * Tiles<NB>::RT + rt) * 16 + p;
+                t.a0[i] = Geo<NB>::addr0(r.b, r.y, r.x) - 2 * RP0 - 2 * REC0;
+                t.a3v[i] = (Geo<NB>::addr3(r.b, r.y, r.x) - RP3 - REC3) | (r.valid ? 1 : 0);
+            }
+    return t;
+}
+template <int NB>
+__device__ const RowTable<NB> g_rows = make_row_table<NB>();
 // float slot of input plane c inside a layer-0 record: planes 0..23 by the inverse of bk_slot_perm, planes 24..26 are
 // k-step 2 of the second channel group (slot 16 + 4kq + 2 for lane quad kq = c - 24)
 __device__ __forceinline__ int in_slot(int c) {
     return c < 24 ? (c & ~15) | ((c & 1) << 3) | (c & 4) | (((c >> 3) & 1) << 1) | ((c >> 1) & 1) : 16 + 4 * (c - 24) + 2;
 }
 
-// wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk).
-// rowa[rt]: byte offset of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4).
+// Summation order (round 4).  Every dot product of a conv layer is TWO fp32 chains -- the taps of the first half of the
+// kernel window (row-major taps 0..4 of 9, 0..11 of 25) and those of the second half -- added once at the end, then the
+// bias: out = (chain(first taps) + chain(second taps)) + bias.  Within a chain the order is the MFMA's: tap by tap, group of
+// 16 input slots by group, k-step j by k-step, lane quad kq ascending (input channel bk_slot_perm(16g + 4kq + j)).  One chain
+// of 1,152 terms (rounds 1-3) put the fp32 kernel 5.8e-5 from the float64 evaluation of the network at |logit| ~ 65, the
+// reference's own fp32 being at 3.5e-5; the rounding error of a chain grows with its length times the size of its partial
+// sums, so two chains of half the length halve it (tools/error_budget.py reproduces the kernel's order on the CPU and prices
+// the variants over the 49,152-position sweep: profiles/r04_error_budget.md).  Every form of the kernel -- 1, 2, 3 boards per
+// workgroup, the cooperative slices -- sums in this same order: bit-identical outputs.
+// The second chain needs a second set of accumulators (64 more registers in the 3-board form, which had 210 of 256 in use):
+// they come out of the activation fragments' double buffer, during the second chain only (conv_layer, A0 / A1).
+//
+// wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk); tile0: the wave's first cout tile.
+// ap[rt]: LDS address of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4); advanced tap by tap and put back at
+// the end (the kernel keeps ONE copy of these pointers alive across the layers).
 // W0..W3: the weight ring, owned by the kernel so that it lives across layers: the last two groups of a layer fetch
 // "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
-// PRELOADED: W0 / W1 already hold this layer's groups 0 / 1.  On return the next layer's groups 0 / 1 sit in W2 / W3
+// W0 / W1 hold this layer's groups 0 / 1 on entry.  On return the next layer's groups 0 / 1 sit in W2 / W3
 // after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
 // F: the wave's tile set (Tiles<NB>, or CoopTiles<SC, SR, RH> of the cooperative small-batch kernel below).
-template <class F, bool FIRST, bool PRELOADED>
-__device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl,
-                                                f32x4 (&acc)[F::RT][F::CTW], int lane, int wm, int wn,
-                                                const int (&rowa)[F::RT], f32x4 (&W0)[F::CTW],
-                                                f32x4 (&W1)[F::CTW], f32x4 (&W2)[F::CTW],
-                                                f32x4 (&W3)[F::CTW]) {
+template <class F, bool FIRST>
+__device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[F::CTW][F::RT], int lane,
+                                           int wm, int tile0, lds_cchar* (&ap)[F::RT], f32x4 (&W0)[F::CTW],
+                                           f32x4 (&W1)[F::CTW], f32x4 (&W2)[F::CTW], f32x4 (&W3)[F::CTW]) {
     constexpr int RT = F::RT, CTW = F::CTW;
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
+    constexpr int HALF = FIRST ? 12 : 5;                // the second chain starts at this tap (layer 0: even, its taps go in pairs)
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
     constexpr int REC = FIRST ? REC0 : REC3, RP = FIRST ? RP0 : RP3;
-    const char* ap[RT];
+    (void)actb;
+    f32x4 part[CTW][RT];                                // the finished first chain
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) ap[rt] = actb + rowa[rt];
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CTW; ++ct) acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    // this wave's cout tiles (CTW*wn ..): 1 KiB per tile and group, 8 KiB per group
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + wn * CTW * 256), 0, 0x7ffffff0, 0x00020000);
+    // this wave's cout tiles (tile0 ..): 1 KiB per tile and group, 8 KiB per group
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + tile0 * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
-    int boff = PRELOADED ? 2 * 8192 : 0;                // scalar: byte offset of the group being fetched
+    int boff = 2 * 8192;                                // scalar: byte offset of the group being fetched
     auto load_w = [&](f32x4 (&W)[CTW]) {
 #if BK_EXP & 2   // timing experiment (make exp EXP=2|3): no weight traffic in the loops -- results are wrong
         (void)W;
@@ -233,71 +265,105 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
 #endif
         boff += 8192;
     };
-    auto read_a = [&](f32x4 (&A)[RT], int imm) {
+    // The activation fragments (one float4 per tile and channel group).  FIRST CHAIN: double-buffered per group (A0 / A1 in
+    // turn; the group's reads are dealt out evenly between its MFMAs) -- `part` is not alive yet, the registers are there.
+    // SECOND CHAIN (3-board workgroups; the other forms have the registers and keep the double buffer: F::DB2): `part` holds
+    // the first chain's sums, so the fragments live in A0 alone: a tile's fragment is dead after
+    // its MFMAs of the group's last k-step, and the next group's is read into the same registers right there, one tile
+    // behind (a read into registers the MFMA just issued still takes its operands from would need wait states).  The
+    // single-buffered body is ~2 % slower than the double-buffered one (its reads crowd into the last k-step;
+    // profiles/r04_two_chains.md), which is why the first chain, 5 of 9 taps, keeps the other.
+    f32x4 A0[RT], A1[RT];
+    auto read_a = [&](f32x4& dst, int rt, int imm) {
 #if BK_EXP & 1   // timing experiment (make exp EXP=1|3): no LDS reads in the loops -- results are wrong
-        (void)A; (void)imm;
+        (void)dst; (void)rt; (void)imm;
 #else
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) A[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + imm);
+        dst = *reinterpret_cast<lds_cf32x4*>(ap[rt] + imm);
 #endif
     };
-    f32x4 A0[RT], A1[RT];                               // activations: ping-pong per group (weights: ring, 2 groups ahead)
 #if BK_EXP & 1
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { A0[rt] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)lane; A1[rt] = f32x4{.5f, .25f, .125f, 1.f} * (float)lane; }
 #endif
 
-    // One group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body for all
-    // taps: the interior tiles always run, every edge tile sits behind a wave-uniform branch (specialised copies of the
-    // tap body -- tens of KB of straight-line MFMAs -- were measured slower).  sx0/sx1/sy0/sy1: skip that edge class.
-    auto do_group = [&](auto GIc, f32x4 (&Wc)[CTW], f32x4 (&Wn)[CTW], int delta, bool sx0, bool sx1, bool sy0, bool sy1) {
+    // One group of 16 input slots (Wc: this group's weights, Wn: receives the group two ahead).  ONE code body per chain for
+    // all its taps: the interior tiles always run, every edge tile sits behind a wave-uniform branch (specialised copies of
+    // the tap body -- tens of KB of straight-line MFMAs -- were measured slower).  sx0/sx1/sy0/sy1: skip that edge class.
+    // DB: the double-buffered body (first chain).
+    auto do_group = [&](auto DBc, auto GIc, f32x4 (&Wc)[CTW], f32x4 (&Wn)[CTW], int delta, bool sx0, bool sx1, bool sy0, bool sy1) {
+        constexpr bool DB = decltype(DBc)::value;
         constexpr int g = decltype(GIc)::value;
         constexpr int JN = (FIRST && g == 1) ? 3 : 4;   // layer 0: planes 16..26 take 3 k-steps
-        f32x4 (&Ac)[RT] = (g & 1) ? A1 : A0;
-        f32x4 (&An)[RT] = (g & 1) ? A0 : A1;
-        auto tiles = [&](int j0, int j1, auto T0, auto T1) {
+        f32x4 (&Ac)[RT] = (DB && (g & 1)) ? A1 : A0;
+        f32x4 (&An)[RT] = (DB && !(g & 1)) ? A1 : A0;
+        // k-steps [j0, j1) of tiles [T0, T1): k-step by k-step over the tiles (an accumulator comes round again after
+        // (T1 - T0) x CTW MFMAs: with two waves on the SIMD a short distance costs -- every 2 MFMAs 496.8 k leaf-evals/s,
+        // every 4 500.9 k, every 10 501.7 k)
+        auto mfmas = [&](int j0, int j1, auto T0, auto T1, auto&& after) {
 #pragma unroll
             for (int j = j0; j < j1; ++j)
 #pragma unroll
-                for (int rt = decltype(T0)::value; rt < decltype(T1)::value; ++rt)
+                for (int rt = decltype(T0)::value; rt < decltype(T1)::value; ++rt) {
 #pragma unroll
                     for (int ct = 0; ct < CTW; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[rt][ct], 0, 0, 0);
+                        acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[ct][j], Ac[rt][j], acc[ct][rt], 0, 0, 0);
+                    after(j, rt);
+                }
         };
-        using IC = std::integral_constant<int, 0>;
-        (void)IC{};
+        // the fragment of tile rt for the next group (the next tap's group 0 behind the last group)
+        auto next_a = [&](int rt) {
+            if (g == G - 1) {
+                ap[rt] += delta;
+                read_a(An[rt], rt, 0);
+            } else {
+                read_a(An[rt], rt, (g + 1) * 64);
+            }
+        };
+        using TA0 = std::integral_constant<int, F::A0>;
+        using TA1 = std::integral_constant<int, F::A1>;
         load_w(Wn);
-        PHASE_FENCE;
-        tiles(0, 1, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
-        if (g == G - 1) {                               // next group is group 0 of the next tap
+        if constexpr (DB) {
+            auto nothing = [](int, int) {};
+            mfmas(0, 1, TA0{}, TA1{}, nothing);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) ap[rt] += delta;
-            read_a(An, 0);
-        } else {
-            read_a(An, (g + 1) * 64);
-        }
-        PHASE_FENCE;
-        tiles(1, JN, std::integral_constant<int, F::A0>{}, std::integral_constant<int, F::A1>{});
+            for (int rt = 0; rt < RT; ++rt) next_a(rt);
+            mfmas(1, JN, TA0{}, TA1{}, nothing);
 #ifndef BK_PHASE_FENCES
-        // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs
-        sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
+            // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs
+            sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
 #endif
-        PHASE_FENCE;
-        if constexpr (F::X0 >= 0) {
-            if (!sx0) tiles(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
             PHASE_FENCE;
-        }
-        if constexpr (F::X1 >= 0) {
-            if (!sx1) tiles(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
+            if constexpr (F::X0 >= 0) { if (!sx0) mfmas(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{}, nothing); }
+            if constexpr (F::X1 >= 0) { if (!sx1) mfmas(0, JN, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{}, nothing); }
+            if constexpr (F::Y0a >= 0) { if (!sy0) mfmas(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{}, nothing); }
+            if constexpr (F::Y1 >= 0) { if (!sy1) mfmas(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{}, nothing); }
+        } else {
+            int prev = -1;
+            // a range of tiles: its MFMAs (if it runs), the reads in the last k-step, each one tile behind
+            auto range = [&](bool run, auto T0, auto T1) {
+                auto behind = [&](int j, int rt) {
+                    if (j == JN - 1) {
+                        if (prev >= 0) next_a(prev);
+                        prev = rt;
+                    }
+                };
+                if (run) {
+                    mfmas(0, JN, T0, T1, behind);
+                } else {
+#pragma unroll
+                    for (int rt = decltype(T0)::value; rt < decltype(T1)::value; ++rt) behind(JN - 1, rt);
+                }
+            };
+            range(true, TA0{}, TA1{});
+#ifndef BK_PHASE_FENCES
+            sched_pattern<(F::A1 - F::A0) * CTW * JN, F::A1 - F::A0 - 1, CTW>(std::make_integer_sequence<int, F::A1 - F::A0 - 1>{});
+#endif
             PHASE_FENCE;
-        }
-        if constexpr (F::Y0a >= 0) {
-            if (!sy0) tiles(0, JN, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
-            PHASE_FENCE;
-        }
-        if constexpr (F::Y1 >= 0) {
-            if (!sy1) tiles(0, JN, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
-            PHASE_FENCE;
+            if constexpr (F::X0 >= 0) range(!sx0, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{});
+            if constexpr (F::X1 >= 0) range(!sx1, std::integral_constant<int, F::X1>{}, std::integral_constant<int, F::X1 + 1>{});
+            if constexpr (F::Y0a >= 0) range(!sy0, std::integral_constant<int, F::Y0a>{}, std::integral_constant<int, F::Y0b>{});
+            if constexpr (F::Y1 >= 0) range(!sy1, std::integral_constant<int, F::Y1>{}, std::integral_constant<int, F::Y1 + 1>{});
+            next_a(prev);                               // the last tile's own (the one read that follows its MFMAs directly)
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -308,8 +374,8 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     using I5 = std::integral_constant<int, 5>;
     using I6 = std::integral_constant<int, 6>;
     using I7 = std::integral_constant<int, 7>;
-    // one tap; PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
-    auto tap = [&](auto PHc, int t) {
+    // one tap; DB: first chain; PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
+    auto tap = [&](auto DBc, auto PHc, int t) {
         const int ky = t / KW, kx = t - ky * KW;
         const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
         const bool lo_x = kx < KW / 2, hi_x = kx > KW / 2, lo_y = ky < KW / 2, hi_y = ky > KW / 2;
@@ -318,101 +384,81 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         const bool sy0 = F::WM_EDGES ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
         if constexpr (FIRST) {
             if constexpr (decltype(PHc)::value == 0) {
-                do_group(I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
-                do_group(I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
             } else {
-                do_group(I0{}, W2, W0, d, sx0, sx1, sy0, sy1);
-                do_group(I1{}, W3, W1, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I0{}, W2, W0, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I1{}, W3, W1, d, sx0, sx1, sy0, sy1);
             }
         } else {
-            do_group(I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
-            do_group(I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
-            do_group(I2{}, W2, W0, d, sx0, sx1, sy0, sy1);
-            do_group(I3{}, W3, W1, d, sx0, sx1, sy0, sy1);
-            do_group(I4{}, W0, W2, d, sx0, sx1, sy0, sy1);
-            do_group(I5{}, W1, W3, d, sx0, sx1, sy0, sy1);
-            do_group(I6{}, W2, W0, d, sx0, sx1, sy0, sy1);
-            do_group(I7{}, W3, W1, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I2{}, W2, W0, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I3{}, W3, W1, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I4{}, W0, W2, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I5{}, W1, W3, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I6{}, W2, W0, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I7{}, W3, W1, d, sx0, sx1, sy0, sy1);
         }
     };
 
-    if constexpr (!PRELOADED) {
-        load_w(W0);
-        load_w(W1);
-    }
-    read_a(A0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) read_a(A0[rt], rt, 0);
+    // first chain: taps [0, HALF), an even number of groups: the second chain finds its first fragments in A0
     if constexpr (FIRST) {
 #pragma unroll 1
-        for (int t = 0; t + 1 < TAPS; t += 2) {
-            tap(I0{}, t);
-            tap(I2{}, t + 1);
+        for (int t = 0; t < HALF; t += 2) {
+            tap(std::true_type{}, I0{}, t);
+            tap(std::true_type{}, I2{}, t + 1);
         }
-        tap(I0{}, TAPS - 1);
     } else {
 #pragma unroll 1
-        for (int t = 0; t < TAPS; ++t) tap(I0{}, t);
+        for (int t = 0; t < HALF; ++t) tap(std::true_type{}, I0{}, t);
     }
-}
-
-#if BK_EXP & 4
-// timing experiment: what a vector wave would issue for its share of a 3x3 layer -- 6 of the 22 positions of the two dropped y-edge
-// tiles, all 128 output channels (a lane = two of them), 6 of 9 taps: per tap and channel group 8 weight loads of 16 B (the group's
-// 8 KiB), per position 4 LDS reads of 16 B (one address for the whole wave) and 16 v_pk_fma_f32.  The operand pairing is arbitrary:
-// only the instruction mix and the traffic are those of a real implementation.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void valu_group(const char* ap, const f32x4 (&W)[8], f32x2 (&acc)[6]) {
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-        f32x4 X[4];
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) X[q] = *reinterpret_cast<const f32x4*>(ap + p * REC3 + q * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 w = W[2 * q + (j >> 1)];
-                acc[p] = __builtin_elementwise_fma(j & 1 ? f32x2{w[2], w[3]} : f32x2{w[0], w[1]}, f32x2{X[q][j], X[q][j]}, acc[p]);
-            }
-    }
-}
-__device__ __forceinline__ void valu_layer(const char* actb, const float* __restrict__ wl, int lane, int vw, f32x2 (&acc)[6]) {
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl), 0, 0x7ffffff0, 0x00020000);
-    // a lane's 16 B of load i: (cout a, cout b) x two input channels -- operand pairs as they are loaded, the activation
-    // broadcast by op_sel: no moves beside the FMAs.  Two weight buffers: the next group is fetched while this one is consumed.
-    f32x4 Wa[8], Wb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) Wa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, 0, 0));
-    int boff = 8192;
-#pragma unroll 1
-    for (int t = 0; t < 6; ++t) {
-        const char* ap = actb + __builtin_amdgcn_readfirstlane((1 + 3 * vw) * RP3 + (1 + t) * REC3);
-#pragma unroll 1
-        for (int g = 0; g < 8; g += 2) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Wb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, boff, 0));
-            valu_group(ap + g * 64, Wa, acc);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Wa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16 + i * 1024, boff + 8192, 0));
-            valu_group(ap + g * 64 + 64, Wb, acc);
-            boff = boff + 16384 < 47 * 8192 ? boff + 16384 : 0;
+        for (int ct = 0; ct < CTW; ++ct) {
+            part[ct][rt] = acc[ct][rt];
+            acc[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    // second chain: taps [HALF, TAPS)
+    using DB2 = std::integral_constant<bool, F::DB2>;
+    if constexpr (FIRST) {
+#pragma unroll 1
+        for (int t = HALF; t < TAPS - 1; t += 2) {
+            tap(DB2{}, I0{}, t);
+            tap(DB2{}, I2{}, t + 1);
+        }
+        tap(DB2{}, I0{}, TAPS - 1);
+    } else {
+#pragma unroll 1
+        for (int t = HALF; t < TAPS; ++t) tap(DB2{}, I0{}, t);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        ap[rt] -= (KW - 1) * (RP + REC);                // back to tap (0,0): the taps advanced it by KW - 1 rows and KW - 1 columns
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) acc[ct][rt] = part[ct][rt] + acc[ct][rt];
     }
 }
-#endif
 
 // bias + ReLU + in-place store: accumulator (rt, ct) of a lane = output slots 16*(CTW*wn + ct) + 4*kq .. +3 of its position
 template <class F>
-__device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[F::RT][F::CTW],
-                                                 const f32x4 (&bv)[F::CTW], const int (&storea)[F::RT]) {
+__device__ __forceinline__ void store_layer(char* actb, const f32x4 (&acc)[F::CTW][F::RT],
+                                                 const f32x4 (&bv)[F::CTW], lds_cchar* const (&ap)[F::RT], int store_c,
+                                                 unsigned valid, int dummy_byte) {
 #pragma unroll
     for (int rt = 0; rt < F::RT; ++rt) {
-        char* wp = actb + storea[rt];
+        // the lane's record of tile rt = its tap-(0,0) read pointer + a per-lane constant; padding rows go to the dummy record
+        typedef __attribute__((address_space(3))) char lds_char;
+        lds_char* wp = (valid >> rt) & 1 ? (lds_char*)(ap[rt]) + store_c : (lds_char*)actb + dummy_byte;
 #pragma unroll
         for (int ct = 0; ct < F::CTW; ++ct) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][ct][e] + bv[ct][e], 0.f);
-            *reinterpret_cast<f32x4*>(wp + ct * 64) = v;
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[ct][rt][e] + bv[ct][e], 0.f);
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(wp + ct * 64) = v;
         }
     }
 }
@@ -483,16 +529,20 @@ __device__ __forceinline__ void run_heads(const bk_eval_args& a, const bk_net_pa
         const int q = lane + 64 * k;
         float d = 0.f;
         if (q < 81) {
+            // four chains -- element e of every float4 of the record -- combined pairwise, then the untied bias (one chain
+            // of 128 terms until round 3: at |logit| ~ 65 its partial sums cost up to 1e-5 of the 1e-4 budget)
             const int y = q / 9, x = q - 9 * y;
             const f32x4* rec = reinterpret_cast<const f32x4*>(actb + G::addr3(board, y, x));
             const f32x4* hw = reinterpret_cast<const f32x4*>(P.head_w);
+            f32x4 d4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
             for (int cc = 0; cc < 32; ++cc) {
                 const f32x4 v = rec[cc];
                 const f32x4 w = hw[cc];
-                d += v.x * w.x; d += v.y * w.y; d += v.z * w.z; d += v.w * w.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d4[e] = __builtin_fmaf(v[e], w[e], d4[e]);
             }
-            d += P.head_b[q];
+            d = ((d4[0] + d4[1]) + (d4[2] + d4[3])) + P.head_b[q];
         }
         s[k] = d;
     }
@@ -519,9 +569,11 @@ __device__ __forceinline__ void run_heads(const bk_eval_args& a, const bk_net_pa
         float w1[81];
 #pragma unroll
         for (int q = 0; q < 81; ++q) w1[q] = P.lin1_wt[q * 64 + lane];
-        float z = P.lin1_b[lane];
+        // four chains (q mod 4; the bias opens chain 0), combined pairwise
+        float z4[4] = {P.lin1_b[lane], 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 81; ++q) z += w1[q] * hv[q];
+        for (int q = 0; q < 81; ++q) z4[q & 3] = __builtin_fmaf(w1[q], hv[q], z4[q & 3]);
+        float z = (z4[0] + z4[1]) + (z4[2] + z4[3]);
         z = fmaxf(z, 0.f);
         const float v = wave_sum(z * P.lin2_w[lane]) + P.lin2_b;
         if (lane == 0 && a.values) a.values[bg] = tanhf(v);
@@ -536,7 +588,8 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     using G = Geo<NB>;
     if constexpr (GATED) {
         if (__builtin_nontemporal_load(a.gate) != a.gate_tag) return;   // uniform over the grid
-        if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.gate_counter, 1u);
+        // "this call was redone": the call's own word in pinned host memory (the host counts the words that changed)
+        if (a.gate_count && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.gate_counter, a.gate_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
@@ -581,55 +634,33 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     }
     stage_input<NB, G::THREADS>(a, actb, b0, nb, tid);
     __syncthreads();
-#if BK_EXP & 4
-    if (NB == 3 && wave >= 8) {
-        // timing experiment: the vector waves' whole life -- the workgroup's barriers in the same order, and in every 3x3 layer
-        // the instruction mix of their share (valu_layer).  A separate path so that no register of the MFMA path stays live here.
-        __syncthreads();                               // layer 0: after the conv
-        for (int i = tid; i < 38 * (REC3 / 16); i += G::THREADS) {
-            const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
-            const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
-            *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();                               // halo cleared
-        __syncthreads();                               // layer 0 stored
-#pragma unroll 1
-        for (int L = 1; L < 7; ++L) {
-            f32x2 va[6];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) va[p] = f32x2{0.f, 0.f};
-#if !(BK_EXP & 8)                                     // EXP=12: idle vector waves -- what the 168-register cap alone costs the MFMA waves
-            valu_layer(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, lane, wave - 8, va);
-#endif
-            __syncthreads();
-            float sink = 0.f;
-#pragma unroll
-            for (int p = 0; p < 6; ++p) sink += va[p][0] + va[p][1];
-            if (sink == 12345.678f) reinterpret_cast<float*>(smem + dummy_byte)[lane] = sink;   // keeps the FMAs alive
-            __syncthreads();
-        }
-        return;
-    }
-#endif
 
     STAMP(1);
     constexpr int RT = F::RT;
     const int kq = lane >> 4;
-    f32x4 acc[RT][F::CTW];
+    f32x4 acc[F::CTW][RT];
     // this lane's positions, decoded ONCE: LDS byte offsets for the activation-fragment reads of layer 0 /
     // layers 1..6 (tap (0,0), chunk kq) and for the epilogue stores (record + this wave's couts)
-    int rowa0[RT], rowa3[RT], storea[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const TileRow fr = tile_row<NB>(wm, rt, lane & 15);
-        rowa0[rt] = G::addr0(fr.b, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
-        rowa3[rt] = G::addr3(fr.b, fr.y, fr.x) - RP3 - REC3 + kq * 16;
-        storea[rt] = fr.valid ? G::addr3(fr.b, fr.y, fr.x) + (16 * F::CTW * wn + 4 * kq) * 4 : dummy_byte;
-    }
+    lds_cchar* ap3[RT];
+    unsigned valid = 0;
+    // epilogue stores: record of (tile, lane) = ap3 + RP3 + REC3 - 16 kq (the tap-(1,1) position) + this wave's couts
+    const int store_c = RP3 + REC3 - kq * 16 + (16 * F::CTW * wn + 4 * kq) * 4;
     f32x4 bv[F::CTW];
-    load_bias<F>(bv, P.bias, wn, kq);
     // ---- layer 0: 5x5, 27 -> 128 ----
-    conv_layer<F, true, true>(actb, P.wfrag, acc, lane, wm, wn, rowa0, Wr0, Wr1, Wr2, Wr3);   // next layer's groups 0/1 end up in Wr2/Wr3
+    const int row_i = wm * RT * 16 + (lane & 15);       // this lane's column of the row table
+    {
+        lds_cchar* ap0[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ap0[rt] = (lds_cchar*)actb + (g_rows<NB>.a0[row_i + rt * 16] + kq * 16);
+        conv_layer<F, true>(actb, P.wfrag, acc, lane, wm, wn * F::CTW, ap0, Wr0, Wr1, Wr2, Wr3);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {                   // (fetched now rather than kept alive through layer 0)
+        const int e = g_rows<NB>.a3v[row_i + rt * 16];
+        ap3[rt] = (lds_cchar*)actb + ((e & ~1) + kq * 16);
+        valid |= (unsigned)(e & 1) << rt;
+    }
+    load_bias<F>(bv, P.bias, wn, kq);                   // behind the conv (its second chain needs the registers): lands during the barrier
     STAMP(2);
     __syncthreads();  // everyone done reading the input planes
     // the 128-ch layout overlaps the input region: the halo must read as zero
@@ -646,7 +677,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     }
     __syncthreads();
     STAMP(3);
-    store_layer<F>(actb, acc, bv, storea);
+    store_layer<F>(actb, acc, bv, ap3, store_c, valid, dummy_byte);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -654,12 +685,12 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn * F::CTW, ap3, Wr2, Wr3, Wr0, Wr1);
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
-        conv_layer<F, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
         STAMP(2 + 4 * L);
         __syncthreads();
         STAMP(3 + 4 * L);
-        store_layer<F>(actb, acc, bv, storea);
+        store_layer<F>(actb, acc, bv, ap3, store_c, valid, dummy_byte);
         STAMP(4 + 4 * L);
         __syncthreads();
         STAMP(5 + 4 * L);
@@ -704,7 +735,7 @@ struct CoopTiles {
     static constexpr int ROWT = 6 / SR;                 // position tiles per workgroup
     static constexpr int RT = ROWT / RH, CTW = 1;
     static constexpr int A0 = 0, A1 = RT, X0 = -1, X1 = -1, Y0a = -1, Y0b = -1, Y1 = -1;
-    static constexpr bool WM_EDGES = false;
+    static constexpr bool WM_EDGES = false, DB2 = true;
     static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = CT * RH, THREADS = 64 * NW;
     static constexpr int XCHG_FLOATS = 2 * 81 * 128;    // per task: two layer parities
@@ -755,13 +786,14 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
     STAMP(1);
 
     const int kq = lane >> 4;
-    f32x4 acc[RT][1];
-    int rowa0[RT], rowa3[RT], storea[RT], xoff[RT];
+    f32x4 acc[1][RT];
+    lds_cchar *ap0[RT], *ap3[RT];
+    int storea[RT], xoff[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const TileRow fr = tile_row<1>(0, sr * F::ROWT + rh * RT + rt, lane & 15);
-        rowa0[rt] = G::addr0(0, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16;
-        rowa3[rt] = G::addr3(0, fr.y, fr.x) - RP3 - REC3 + kq * 16;
+        ap0[rt] = (lds_cchar*)actb + (G::addr0(0, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16);
+        ap3[rt] = (lds_cchar*)actb + (G::addr3(0, fr.y, fr.x) - RP3 - REC3 + kq * 16);
         storea[rt] = fr.valid ? G::addr3(0, fr.y, fr.x) + (16 * wn + 4 * kq) * 4 : dummy_byte;
         xoff[rt] = fr.valid ? (9 * fr.y + fr.x) * 128 + 16 * wn + 4 * kq : -1;
     }
@@ -779,7 +811,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
         for (int rt = 0; rt < RT; ++rt) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[rt][0][e] + bv[0][e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[0][rt][e] + bv[0][e], 0.f);
             *reinterpret_cast<f32x4*>(actb + storea[rt]) = v;
             if (xoff[rt] >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xr, xoff[rt] * 4, par, SC1);
         }
@@ -834,7 +866,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 
     // ---- layer 0: 5x5, 27 -> 128 ----
     load_bias<F>(bv, P.bias, wn, kq);
-    conv_layer<F, true, true>(actb, P.wfrag, acc, lane, 0, wn, rowa0, Wr0, Wr1, Wr2, Wr3);
+    conv_layer<F, true>(actb, P.wfrag, acc, lane, 0, wn, ap0, Wr0, Wr1, Wr2, Wr3);
     STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::L3_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -844,7 +876,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
-        conv_layer<F, false, true>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, 0, wn, rowa3, Wr2, Wr3, Wr0, Wr1);
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, 0, wn, ap3, Wr2, Wr3, Wr0, Wr1);
         STAMP(2 + 4 * L);
         __syncthreads();
         if (!exchange(L)) return;
@@ -908,9 +940,7 @@ constexpr long tile_taps(int kw) {
     const int ny = (F::Y0a >= 0 ? F::Y0b - F::Y0a : 0) + (F::Y1 >= 0);
     return (long)(F::A1 - F::A0) * taps + (long)(nx + ny) * (taps - skip);
 }
-#if !(BK_EXP & 4)
 static_assert(tile_taps<Tiles<3>>(3) == 63 && tile_taps<Tiles<3>>(5) == 170, "3 boards: 63 of 72 / 170 of 200 tile-taps");
-#endif
 static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 54, "2 boards: 87 of 99; 1 board: all 54");
 // FLOP the matrix unit executes for ONE net on one NB-board workgroup: per (tile, tap) 7 k-steps in layer 0 (28 input
 // slots) resp. 32 in a 3x3 layer, x 8 cout tiles, of v_mfma_f32_16x16x4_f32 (2 * 16 * 16 * 4 = 2,048 FLOP each)

@@ -79,15 +79,24 @@ def test_playout_positions(engine):
     assert np.abs(out["value"] - p["values"]).max() < TOL_VALUE
 
 
-def test_vs_oracle_random_inputs(engine, oracle):
-    """iid random planes (values 0..7): far from the golden distribution, checked against the oracle.
-    Logits on such inputs are much larger than on real positions, so the bound scales with them."""
+def test_vs_oracle_random_inputs(engine, oracle, weights):
+    """iid random planes (values 0..7): far from the golden distribution.  Logits on such inputs are much larger than on real
+    positions (|logit| up to ~110), so the bound scales with them.  Ground truth is the float64 evaluation of the reference's
+    operators (oracle/torch_ref.py in double): against it the kernel must stay within the scaled tolerance -- two fp32
+    evaluations that sum in different orders (the kernel's two chains per dot product, the C oracle's single one) each carry
+    their own rounding error, so between THEM the bound is 1.5x."""
+    import torch
+    from oracle.torch_ref import TorchPolicy, TorchValue
     rng = np.random.default_rng(7)
     x = rng.integers(0, 8, size=(96, 27, 9, 9)).astype(np.float32)
     out = engine.eval(x, logits=True, probs=False, value=True)
-    lg = oracle[0](x)
-    scale = max(1.0, np.abs(lg).max() / 50.0)
-    assert np.abs(out["logits"] - lg).max() < TOL_LOGIT * scale
+    xd = torch.from_numpy(x).double()
+    lg64 = TorchPolicy(weights[0]).double()(xd).numpy()
+    va64 = TorchValue(weights[1]).double()(xd).numpy()
+    scale = max(1.0, np.abs(lg64).max() / 50.0)
+    assert np.abs(out["logits"] - lg64).max() < TOL_LOGIT * scale
+    assert np.abs(out["value"] - va64).max() < TOL_VALUE
+    assert np.abs(out["logits"] - oracle[0](x)).max() < 1.5 * TOL_LOGIT * scale
     assert np.abs(out["value"] - oracle[1](x)).max() < 1e-3
 
 
@@ -738,4 +747,26 @@ def test_one_request_of_32768_positions(precision):
     for k in ref:
         assert np.array_equal(big[k].view(np.uint32), ref[k].view(np.uint32)), k
         assert np.array_equal(dev[k].cpu().numpy().view(np.uint32), ref[k].view(np.uint32)), k
+    eng.close()
+
+
+def test_kernel_order_emulation_matches_the_kernel(weights):
+    """tools/emu/kernel_emu.c restates the fp32 kernel's SUMMATION ORDER on the CPU (two chains per conv dot product over the
+    halves of the window, MFMA k order inside a chain, four-chain heads) so that tools/error_budget.py can price orders on
+    the 49,152-position sweep without a GPU.  That is only worth anything if it is the kernel's order: the logits of 64
+    sweep-worst positions must equal the emulation BIT FOR BIT, in every form of the kernel (one request: 3-board workgroups;
+    B = 2: two boards; one at a time: the cooperative slices), and the value head's pre-tanh sums give the kernel's values."""
+    from bokego_amd.engine import LeafEngine
+    chk = np.load(os.path.join(GOLDEN, "emu_check.npz"))
+    x = chk["features"]
+    eng = LeafEngine(weights[0], weights[1], max_batch=64)
+    out = eng.eval(x, logits=True, probs=False, value=True)
+    assert np.array_equal(out["logits"], chk["logits_r4"])
+    assert not np.array_equal(out["logits"], chk["logits_r3"])           # the one-chain order of rounds 1-3 is a different sum
+    assert np.abs(out["value"] - np.tanh(chk["value_pre_tanh_r4"].astype(np.float64))).max() < 1.5e-7
+    two = eng.eval(x[:2], logits=True, probs=False, value=True)
+    assert np.array_equal(two["logits"], chk["logits_r4"][:2])
+    for i in (0, 17, 63):
+        one = eng.eval(x[i:i + 1], logits=True, probs=False, value=True)
+        assert np.array_equal(one["logits"], chk["logits_r4"][i:i + 1]) and one["value"][0] == out["value"][i]
     eng.close()

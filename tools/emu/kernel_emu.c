@@ -29,6 +29,7 @@ typedef struct {
     float lin2_b;
 } emu_net;
 
+int emu_split3 = 5, emu_split5 = 12;   /* first tap of the second chain (3x3 / 5x5 layers) */
 static void conv_point(const float* in /*[C][81]*/, int C, int kw, int y, int x, const float* w /*[taps][nk][128]*/, const int32_t* ch,
                        int nk, const float* bias, int two_acc, int exact, float* out /*[128]*/) {
     const int r = kw / 2;
@@ -57,7 +58,8 @@ static void conv_point(const float* in /*[C][81]*/, int C, int kw, int y, int x,
     for (int t = 0; t < kw * kw; ++t) {
         const int yy = y + t / kw - r, xx = x + t % kw - r;
         if (yy < 0 || yy > 8 || xx < 0 || xx > 8) continue;
-        float* a = acc[two_acc ? (t & 1) : 0];
+        /* two_acc: 1 = by tap parity, 2 = first / second half of the taps as the kernel splits them (3x3: 0..4 | 5..8, 5x5: 0..11 | 12..24) */
+        float* a = acc[two_acc == 1 ? (t & 1) : two_acc >= 2 ? (t >= (kw == 3 ? emu_split3 : emu_split5)) : 0];
         const float* wt = w + (size_t)t * nk * 128;
         for (int k = 0; k < nk; ++k) {
             const float xv = in[ch[k] * 81 + yy * 9 + xx];
@@ -76,9 +78,10 @@ static void conv_point(const float* in /*[C][81]*/, int C, int kw, int y, int x,
  * (policy: the logits; value: the input of the MLP before its ReLU); value_out: {pre-tanh, tanh} (value net only) */
 void emu_forward(const emu_net* N, const float* planes, int two_acc_mask, int exact_mask, int head_mode /*0 chain, 1 four chains, 2 f64*/,
                  int lin_mode, float* acts, float* head_out, float* value_out) {
+    const int split_kind = (two_acc_mask >> 8) ? 2 : 1;   /* bit 8 of the mask: halves instead of parity */
     float a[128 * 81], b[128 * 81], pt[128];
     for (int q = 0; q < 81; ++q) {
-        conv_point(planes, 27, 5, q / 9, q % 9, N->w0, N->ch0, 27, N->bias, two_acc_mask & 1, exact_mask & 1, pt);
+        conv_point(planes, 27, 5, q / 9, q % 9, N->w0, N->ch0, 27, N->bias, (two_acc_mask & 1) ? split_kind : 0, exact_mask & 1, pt);
         for (int c = 0; c < 128; ++c) a[c * 81 + q] = pt[c];
     }
     if (acts) memcpy(acts, a, sizeof a);
@@ -86,7 +89,7 @@ void emu_forward(const emu_net* N, const float* planes, int two_acc_mask, int ex
     for (int L = 1; L < 7; ++L) {
         for (int q = 0; q < 81; ++q) {
             conv_point(cur, 128, 3, q / 9, q % 9, N->w3 + (size_t)(L - 1) * 9 * 128 * 128, N->ch3, 128, N->bias + L * 128,
-                       (two_acc_mask >> L) & 1, (exact_mask >> L) & 1, pt);
+                       ((two_acc_mask >> L) & 1) ? split_kind : 0, (exact_mask >> L) & 1, pt);
             for (int c = 0; c < 128; ++c) nxt[c * 81 + q] = pt[c];
         }
         if (acts) memcpy(acts + (size_t)L * 128 * 81, nxt, sizeof a);
