@@ -425,6 +425,40 @@ def launch(args, argv):
     return 0 if failed is None and all(p.returncode == 0 for p in procs) else 1
 
 
+_CPUS_BEFORE_PINNING = None
+
+
+def leave_the_group(dist, rank, world, pids=None):
+    """The last collective is behind us: barrier, tear the group down; every rank but 0 returns False (and exits); rank 0 waits
+    until the others are gone, takes back the CPUs it had before it pinned itself to its slice, and returns True -- it then
+    runs the CPU legs and the counter passes alone, with the host's cores and the GPUs to itself."""
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return False
+    if world > 1:
+        t_end = time.time() + 15
+        while pids and time.time() < t_end:
+            alive = []
+            for p in pids:
+                try:
+                    os.kill(p, 0)
+                    alive.append(p)
+                except OSError:
+                    pass
+            pids = alive
+            time.sleep(0.1)
+        if not pids:
+            time.sleep(0.5)
+        if _CPUS_BEFORE_PINNING:
+            try:
+                os.sched_setaffinity(0, _CPUS_BEFORE_PINNING)
+            except OSError:
+                pass
+    return True
+
+
 def launch_selftest(args):
     """What a rank does under BK_BENCH_LAUNCH_SELFTEST (tests/test_bench_cpu.py: the launcher without a GPU): join a
     gloo group through the launcher's environment, all-reduce, rank 0 prints one line.  `fail:R` makes rank R exit 3
@@ -438,13 +472,24 @@ def launch_selftest(args):
     dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t)
-    cpus = [None] * world
+    cpus, pids = [None] * world, [None] * world
     dist.all_gather_object(cpus, format_cpulist(os.sched_getaffinity(0)))
-    if rank == 0:
-        print(json.dumps({"n_gpus": world, "collective_ranks_seen": dist.get_world_size(), "collective_backend": "gloo",
-                          "sum_of_ranks_plus_1": float(t.item()), "rank_cpus": cpus, "steps": args.steps,
-                          "host_threads": os.environ.get("BK_BENCH_HOST_THREADS")}), flush=True)
-    dist.destroy_process_group()
+    dist.all_gather_object(pids, os.getpid())
+    seen = dist.get_world_size()
+    # the real run's exit protocol: the other ranks leave, rank 0 goes on alone (CPU legs, counter passes) and prints the line
+    if not leave_the_group(dist, rank, world, [p for p in pids if p != os.getpid()]):
+        return 0
+    gone = []
+    for p in pids[1:]:
+        try:
+            os.kill(p, 0)
+            gone.append(False)
+        except OSError:
+            gone.append(True)
+    print(json.dumps({"n_gpus": world, "collective_ranks_seen": seen, "collective_backend": "gloo",
+                      "sum_of_ranks_plus_1": float(t.item()), "rank_cpus": cpus, "steps": args.steps,
+                      "host_threads": os.environ.get("BK_BENCH_HOST_THREADS"), "other_ranks_gone": gone,
+                      "rank0_cpus_for_the_cpu_legs": format_cpulist(os.sched_getaffinity(0))}), flush=True)
     return 0
 
 
@@ -540,7 +585,7 @@ def fold_counter_rows(rows, tot):
     return True
 
 
-def live_counters(batch, precision, timeout_s=150):
+def live_counters(batch, precision, timeout_s=150, device=0):
     """The hardware counters of the timed launch, measured in THIS run: one rocprofv3 --pmc pass per counter group (separate
     passes, as MI355X_MICROARCH.md's HBM section prescribes) around a child process -- `python3 bench.py --pmc-child`, started
     after the timed region -- that issues the same B-position launch a few times.  Per step (= every launch of the step: the
@@ -559,9 +604,13 @@ def live_counters(batch, precision, timeout_s=150):
     for ctrs in PMC_PASSES:
         d = tempfile.mkdtemp(prefix="bk_pmc_", dir="/tmp")
         try:
+            # (the child is not a rank: none of the parent's rendezvous / pinning variables)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                                    "MASTER_PORT", "BK_BENCH_CPUS", "BK_BENCH_HOST_THREADS", "BK_BENCH_PINNED_BY",
+                                                                    "OMP_NUM_THREADS", "TORCHELASTIC_RUN_ID")}
             r = subprocess.run([exe, "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                                "--pmc-child", "--batch", str(batch), "--precision", precision],
-                               capture_output=True, text=True, timeout=timeout_s, cwd=REPO, env=dict(os.environ, TMPDIR="/tmp"))
+                                "--pmc-child", "--batch", str(batch), "--precision", precision, "--pmc-device", str(device)],
+                               capture_output=True, text=True, timeout=timeout_s, cwd=REPO, env=dict(env, TMPDIR="/tmp"))
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
@@ -597,7 +646,8 @@ def pmc_child(args):
     from bokego_amd.bkw import load_bkw
     from bokego_amd.engine import LeafEngine
     g = os.path.join(REPO, "tests", "golden")
-    eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw")), device_id=0,
+    torch.cuda.set_device(args.pmc_device)
+    eng = LeafEngine(load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw")), device_id=args.pmc_device,
                      max_batch=args.batch, precision=args.precision)
     x = torch.from_numpy(make_workload(args.batch, 0)[0]).cuda()
     for _ in range(8):
@@ -672,6 +722,7 @@ def main():
     ap.add_argument("--selfplay-games", type=int, default=512, help="games of the secondary configs[3] measurement (512 = the config; tests use fewer)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes (roofline.traffic etc. then come from the committed summary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--plan", action="store_true", help="print the N-rank launch plan (devices, CPU slices, port) and exit; no GPU call")
     args = ap.parse_args()
 
@@ -686,6 +737,8 @@ def main():
             os.environ["BK_BENCH_PINNED_BY"] = "rank"
         except (IndexError, ValueError, OSError):
             pass
+    global _CPUS_BEFORE_PINNING
+    _CPUS_BEFORE_PINNING = os.sched_getaffinity(0)
     if "BK_BENCH_CPUS" in os.environ:          # pin before torch starts its thread pools
         try:
             os.sched_setaffinity(0, parse_cpulist(os.environ["BK_BENCH_CPUS"]))
@@ -863,12 +916,32 @@ def main():
         sp["games_per_min"] = sp[args.precision]["games_per_min"]
         sp["stats_allreduce_ms"] = sp[args.precision]["stats_allreduce_ms"]
 
+    # ---- the collectives are over: the other ranks leave, rank 0 finishes the line ---------------------------------------
+    # north_star: "1/2/4/8-GPU self-play throughput reported next to the reference CPU path timed on the host cores (core
+    # count stated) in the same run" -- so the CPU legs and the counter passes run at ANY world size, on rank 0, once the
+    # other ranks have let go of the host's cores and of the GPUs (they exit here; under torch.distributed.run the agent
+    # simply waits for rank 0).  Rank 0 takes the CPUs it had before it pinned itself to its slice: the CPU legs then see the
+    # host exactly as a 1-GPU run does.
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    dist_backend = backend if dist is not None else None
+    rank0_cpus = format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None
+    others = None
+    if dist is not None:
+        others = [None] * world
+        dist.all_gather_object(others, os.getpid())
+        others = [p for p in others if p != os.getpid()]
+    if rank != 0:
+        eng.close()                              # the GPU is let go of before the group is: rank 0's counter passes come next
+    if not leave_the_group(dist, rank, world, others):
+        return
+    dist = None
+
     live = None
-    if rank == 0 and world == 1 and not args.no_live_pmc:
-        live = live_counters(args.batch, args.precision)
+    if not args.no_live_pmc:
+        live = live_counters(args.batch, args.precision, device=local_rank)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         cpu = cpu_baseline(pw, vw, x_host, head_logits, head_values)
         if sp is not None:
             sp["cpu_baseline"] = selfplay_cpu_baseline(cpu["cores"])
@@ -893,21 +966,19 @@ def main():
             "cpu_baseline": cpu,
             "selfplay": sp,
             "small_batch_latency": small,
-            "collective_ranks_seen": dist.get_world_size() if dist is not None else 1,
-            "collective_backend": (backend if dist is not None else None),
+            "collective_ranks_seen": ranks_seen,
+            "collective_backend": dist_backend,
             "per_rank_leaf_evals_per_s": per_rank,
             "launched_by": ("torch.distributed.run" if os.environ.get("BK_BENCH_PINNED_BY") == "rank" or
                             ("TORCHELASTIC_RUN_ID" in os.environ and "BK_BENCH_CPUS" not in os.environ) else
                             "bench.py launcher" if "BK_BENCH_CPUS" in os.environ else "direct"),
-            "rank0_cpus": format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None,
+            "rank0_cpus": rank0_cpus,
             "host_buffer_e2e_leaf_evals_per_s": e2e,
             "host_buffer_e2e_u8_pipelined_leaf_evals_per_s": e2e_u8,
             "host_positions_e2e_pipelined_leaf_evals_per_s": e2e_pos,
         }
         print(json.dumps(line), flush=True)
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

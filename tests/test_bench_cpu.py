@@ -78,6 +78,41 @@ def test_launch_plan_splits_whole_cores_by_numa_node():
     assert all(r["numa_node"] == 1 for r in reh["ranks"])
 
 
+def test_launch_plan_for_eight_gpus_on_a_small_cpu_share():
+    """the driver's 8-GPU run may own far fewer CPUs than the node has.  2 NUMA nodes, four GPUs each, and
+    (a) an affinity mask of 16 CPUs = 8 cores x 2 threads, 4 cores per node, 16-CPU quota: one whole core per rank, local to
+    its GPU; (b) the same mask on ONE node only (the other node's GPUs have no local CPU): a flat split, 2 CPUs each; (c) 8 CPUs
+    in all: one each.  Never a rank without a CPU, never a CPU handed out twice, one host thread per rank."""
+    core_of = {c: c % 128 for c in range(256)}
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+
+    def check(plan, n_each):
+        seen = set()
+        for r in plan["ranks"]:
+            cpus = bench.parse_cpulist(r["cpus"])
+            assert len(cpus) == n_each == r["n_cpus"] and r["host_threads"] == 1
+            assert not seen & set(cpus)
+            seen |= set(cpus)
+        return seen
+
+    allowed = [0, 1, 2, 3, 128, 129, 130, 131, 64, 65, 66, 67, 192, 193, 194, 195]
+    plan = bench.launch_plan(8, allowed=allowed, gpu_nodes=gpus, node_cpus=node_cpus, quota=16, core_of=core_of)
+    assert check(plan, 2) == set(allowed)
+    for r in plan["ranks"]:
+        cpus = bench.parse_cpulist(r["cpus"])
+        assert r["numa_node"] == (0 if r["rank"] < 4 else 1) and set(cpus) <= set(node_cpus[r["numa_node"]])
+        assert len({core_of[c] for c in cpus}) == 1                       # the two threads of one core
+    one_node = list(range(0, 8)) + list(range(128, 136))
+    plan = bench.launch_plan(8, allowed=one_node, gpu_nodes=gpus, node_cpus=node_cpus, quota=16, core_of=core_of)
+    assert check(plan, 2) == set(one_node) and all(r["numa_node"] == -1 for r in plan["ranks"])
+    plan = bench.launch_plan(8, allowed=range(8), gpu_nodes=gpus, node_cpus=node_cpus, quota=8, core_of=core_of)
+    assert check(plan, 1) == set(range(8))
+    # fewer CPUs than ranks: the ranks share what there is (every rank still has somewhere to run)
+    plan = bench.launch_plan(8, allowed=range(4), gpu_nodes=[], node_cpus={}, quota=4, core_of={})
+    assert all(r["n_cpus"] >= 1 and r["host_threads"] == 1 for r in plan["ranks"])
+
+
 def test_plan_flag_prints_the_plan_and_starts_nothing():
     out = _run_bench(["--gpus", "4", "--steps", "3", "--plan"])
     assert out.returncode == 0, out.stderr[-1000:]
@@ -102,6 +137,24 @@ def test_launcher_starts_n_ranks_and_relays_one_line():
     cpus = [set(bench.parse_cpulist(c)) for c in d["rank_cpus"]]
     if len(os.sched_getaffinity(0)) >= 3:
         assert not (cpus[0] & cpus[1]) and not (cpus[1] & cpus[2]) and set().union(*cpus) <= set(os.sched_getaffinity(0))
+    # the exit protocol of the real run: the other ranks were gone and rank 0 had the host's CPUs back before it printed
+    assert d["other_ranks_gone"] == [True, True]
+    assert set(bench.parse_cpulist(d["rank0_cpus_for_the_cpu_legs"])) == set(os.sched_getaffinity(0))
+
+
+def test_eight_ranks_rendezvous_leave_and_rank_0_finishes_alone():
+    """the first 8-rank run will be the driver's.  Everything of it that needs no GPU, at 8 ranks: the plan,
+    eight fresh children, the gloo rendezvous, a collective, the other seven leaving after the last collective and rank 0
+    taking the host's CPUs back for the CPU legs, one line relayed."""
+    out = _run_bench(["--gpus", "8", "--steps", "20", "--warmup", "5"], env={"BK_BENCH_LAUNCH_SELFTEST": "1"}, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["collective_ranks_seen"] == 8 and d["sum_of_ranks_plus_1"] == 36.0 and d["steps"] == 20
+    assert d["other_ranks_gone"] == [True] * 7
+    assert all(bench.parse_cpulist(c) for c in d["rank_cpus"])           # no rank without a CPU
+    assert set(bench.parse_cpulist(d["rank0_cpus_for_the_cpu_legs"])) == set(os.sched_getaffinity(0))
 
 
 def test_launcher_returns_nonzero_and_ends_the_others_when_a_rank_fails():

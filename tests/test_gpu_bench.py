@@ -75,7 +75,16 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collective_ranks_seen"] == 2 and d["collective_backend"] == ("nccl" if real else "gloo")
     assert len(d["per_rank_leaf_evals_per_s"]) == 2 and all(v > 1e4 for v in d["per_rank_leaf_evals_per_s"])
-    assert d["launched_by"] == "bench.py launcher" and d["cpu_baseline"] is None
+    assert d["launched_by"] == "bench.py launcher"
+    # the N-rank line is complete: once the collectives are over the other ranks leave and rank 0 times
+    # the reference's CPU path on the host's cores and takes the counters, as a 1-GPU run does
+    cpu = d["cpu_baseline"]
+    assert cpu and cpu["value"] > 100 and cpu["cores"] >= 1 and cpu["kind"] == "port"
+    assert d["config"]["parity_workload_sample"]["max_abs_dlogit_vs_oracle"] < 2e-4
+    assert d["selfplay"]["cpu_baseline"]["games_per_min"] > 0 and d["selfplay"]["cpu_baseline"]["cores"] == cpu["cores"]
+    r = d["roofline"]
+    if r["pmc_file_fallback"] is None:
+        assert r["traffic_source"].startswith("measured in this run") and 40e6 < r["traffic"] < 300e6
     sp = d["selfplay"]
     assert sp["f32"]["games"] == 32 and sp["games_per_min"] > 0 and sp["stats_allreduce_ms"] > 0
     assert sp["f32"]["first_move_hist_sum"] == 32
