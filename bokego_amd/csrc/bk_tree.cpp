@@ -577,6 +577,13 @@ struct bk_pool {
     std::vector<int> pol_off, val_off;
     int threads = 1;
     std::vector<int> lane_items[64];   // scratch of run_lanes
+    // in-batch de-duplication (bk_pool_set_dedup): rows of one batch that are the same position record -- games that are still in
+    // the same opening -- travel once; row_of[a] = for the a-th active game the batch row of each of its request rows (policy
+    // rows first, then value rows), as laid out by collect_dedup
+    bool dedup = false;
+    std::vector<std::vector<int>> row_of;
+    std::vector<bk_pos> uniq_pol, uniq_val;
+    uint64_t rows_requested = 0, rows_sent = 0;
 };
 
 extern "C" {
@@ -924,7 +931,134 @@ int bk_pool_collect(bk_pool* p, uint8_t* feats, int cap, int* n_policy) {
     return collect_impl(p, cap, n_policy, [feats](bk_pos* pos, size_t row) { bk_pos_features_u8(pos, feats + row * 2187, 0); });
 }
 
+namespace {
+// FNV-1a over the record's 8-byte words (the record is 192 bytes, 8-byte aligned)
+inline uint64_t record_hash(const bk_pos& q) {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(&q);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(bk_pos) / 8; ++i) h = (h ^ w[i]) * 1099511628211ull;
+    return h;
+}
+
+// bk_pool_collect_pos with in-batch de-duplication.  Two request rows are the same row when their 192-byte records are equal
+// byte for byte -- stones, ko, last move, turn AND the (history-dependent) liberty cache: everything the planes are computed
+// from -- so the networks' outputs for them are the same bits, whichever game's row is evaluated.  A value row whose record
+// also travels as a policy row takes that row's value (a policy row runs both nets).  The batch limits (cap, task_cap) count
+// what actually travels.  Per-game counters and records are those of the logical requests: a game cannot tell.
+int collect_dedup(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
+    const int G = (int)p->games.size();
+    std::vector<char> wants(G, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p->row_cap == 0 || cap < p->row_cap) {
+        p->row_cap = cap;
+        for (auto& gm : p->games) {
+            gm.prm.speculate_rows = std::min(gm.prm.speculate_rows, cap);
+            gm.row_cap = cap;
+        }
+    }
+    run_lanes(p, G, [](int g) { return g; }, [&](int g) {
+        Game& gm = p->games[g];
+        if (gm.state != S_DONE && !gm.has_request()) wants[g] = gm.advance() ? 1 : 0;
+        else if (gm.has_request()) wants[g] = 1;
+        if (wants[g]) {                                  // the history-dependent half of features(): see bk_pool_collect_pos
+            uint8_t libs[81];
+            for (int id : gm.req_policy) bk_pos_liberties(&gm.poses[id], libs);
+            for (int id : gm.req_value) bk_pos_liberties(&gm.poses[id], libs);
+        }
+    });
+    const auto t1 = std::chrono::steady_clock::now();
+    p->t_advance += std::chrono::duration<double>(t1 - t0).count();
+    p->active.clear();
+    p->row_of.clear();
+    p->uniq_pol.clear();
+    p->uniq_val.clear();
+    // record hash -> index into uniq_pol (kind 0) / uniq_val (kind 1); collisions resolved by comparing the records
+    std::unordered_multimap<uint64_t, std::pair<int, int>> index;
+    auto find = [&](const bk_pos& q, uint64_t h, int kind) {
+        auto range = index.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second.first == kind &&
+                std::memcmp(&(kind ? p->uniq_val : p->uniq_pol)[it->second.second], &q, sizeof(bk_pos)) == 0)
+                return it->second.second;
+        return -1;
+    };
+    const int start = p->task_cap > 0 ? p->first % G : 0;
+    int first_left = -1;
+    std::vector<int> rows;      // of the game being placed: >= 0 policy index, < 0: -(value index) - 1
+    std::vector<std::pair<uint64_t, std::pair<int, int>>> added;
+    for (int k = 0; k < G; ++k) {
+        const int g = start + k < G ? start + k : start + k - G;
+        if (!wants[g]) continue;
+        Game& gm = p->games[g];
+        rows.clear();
+        added.clear();
+        const size_t np0 = p->uniq_pol.size(), nv0 = p->uniq_val.size();
+        for (int id : gm.req_policy) {
+            const bk_pos& q = gm.poses[id];
+            const uint64_t h = record_hash(q);
+            int at = find(q, h, 0);
+            if (at < 0) {
+                at = (int)p->uniq_pol.size();
+                p->uniq_pol.push_back(q);
+                index.emplace(h, std::make_pair(0, at));
+                added.push_back({h, {0, at}});
+            }
+            rows.push_back(at);
+        }
+        for (int id : gm.req_value) {
+            const bk_pos& q = gm.poses[id];
+            const uint64_t h = record_hash(q);
+            int at = find(q, h, 0);
+            if (at >= 0) { rows.push_back(at); continue; }       // travels as a policy row: its value comes with it
+            at = find(q, h, 1);
+            if (at < 0) {
+                at = (int)p->uniq_val.size();
+                p->uniq_val.push_back(q);
+                index.emplace(h, std::make_pair(1, at));
+                added.push_back({h, {1, at}});
+            }
+            rows.push_back(-at - 1);
+        }
+        const int npol = (int)p->uniq_pol.size(), nval = (int)p->uniq_val.size();
+        const bool over = p->task_cap > 0 && !p->active.empty() && 2 * npol + nval > p->task_cap;
+        if (npol + nval > cap || over) {                     // does not fit: take its new rows out again
+            for (auto& a : added) {
+                auto range = index.equal_range(a.first);
+                for (auto it = range.first; it != range.second; ++it)
+                    if (it->second == a.second) { index.erase(it); break; }
+            }
+            p->uniq_pol.resize(np0);
+            p->uniq_val.resize(nv0);
+            if (first_left < 0) first_left = g;
+            continue;
+        }
+        p->active.push_back(g);
+        p->row_of.push_back(rows);
+        p->rows_requested += rows.size();
+        gm.n_requests += 1;
+    }
+    if (first_left >= 0) p->first = first_left;
+    const int npol = (int)p->uniq_pol.size(), nval = (int)p->uniq_val.size();
+    if (npol) std::memcpy(out, p->uniq_pol.data(), (size_t)npol * sizeof(bk_pos));
+    if (nval) std::memcpy(out + npol, p->uniq_val.data(), (size_t)nval * sizeof(bk_pos));
+    for (auto& rows_a : p->row_of)
+        for (int& r : rows_a)
+            if (r < 0) r = npol + (-r - 1);
+    p->rows_sent += (uint64_t)(npol + nval);
+    p->t_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    *n_policy = npol;
+    return npol + nval;
+}
+}  // namespace
+
+void bk_pool_set_dedup(bk_pool* p, int on) { p->dedup = on != 0; }
+void bk_pool_dedup_rows(const bk_pool* p, uint64_t* requested, uint64_t* sent) {
+    *requested = p->rows_requested;
+    *sent = p->rows_sent;
+}
+
 int bk_pool_collect_pos(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
+    if (p->dedup) return collect_dedup(p, out, cap, n_policy);
     // the history-dependent half of nnet.features() -- the lazy liberty-cache refresh, go.py:220-243 -- runs
     // here, on the node itself (its children inherit the refreshed cache, as with bk_pool_collect); the
     // planes are then a pure function of the record and are computed by the consumer (the GPU encoder)
@@ -1003,8 +1137,21 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
         nval += (int)p->games[p->active[a]].req_value.size();
     }
     const int A = (int)p->active.size();
+    const bool mapped = p->dedup && p->row_of.size() == p->active.size();   // the batch was laid out by collect_dedup
     auto deliver_game = [&](int a) {
         Game& gm = p->games[p->active[a]];
+        if (mapped) {
+            const std::vector<int>& rows = p->row_of[a];
+            const size_t np_ = gm.req_policy.size();
+            for (size_t i = 0; i < np_; ++i) {
+                gm.deliver_policy(gm.req_policy[i], probs + (size_t)rows[i] * 81);
+                if (values) gm.deliver_value(gm.req_policy[i], values[rows[i]]);
+            }
+            for (size_t i = 0; i < gm.req_value.size(); ++i) gm.deliver_value(gm.req_value[i], values[rows[np_ + i]]);
+            gm.req_policy.clear();
+            gm.req_value.clear();
+            return;
+        }
         for (size_t i = 0; i < gm.req_policy.size(); ++i) {
             const int row = p->pol_off[a] + (int)i;
             gm.deliver_policy(gm.req_policy[i], probs + (size_t)row * 81);
@@ -1019,6 +1166,7 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
     if (lanes && npol + nval >= 64) run_lanes(p, A, [&](int a) { return p->active[a]; }, deliver_game);
     else for (int a = 0; a < A; ++a) deliver_game(a);
     p->active.clear();
+    p->row_of.clear();
     p->t_deliver += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -55,6 +55,8 @@ TREE_SYMBOLS = {
     "bk_pool_collect_pos": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
     "bk_pool_phase_seconds": (None, [_VP, _VP]),
+    "bk_pool_set_dedup": (None, [_VP, ctypes.c_int]),
+    "bk_pool_dedup_rows": (None, [_VP, _VP, _VP]),
     "bk_team_selftest": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "bk_team_selftest_concurrent": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "bk_pool_set_task_cap": (None, [_VP, ctypes.c_int]),
@@ -150,6 +152,16 @@ class GamePool:
     def set_task_cap(self, tasks):
         """Soft limit of a batch in network tasks (bk_pool_set_task_cap); 0: none."""
         self._lib.bk_pool_set_task_cap(self._h, int(tasks))
+
+    def set_dedup(self, on=True):
+        """In-batch de-duplication of collect_positions() (bk_pool_set_dedup): equal records travel once."""
+        self._lib.bk_pool_set_dedup(self._h, int(bool(on)))
+
+    def dedup_rows(self):
+        """(rows the games asked for, rows that travelled) since the pool was created, with de-duplication on."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._lib.bk_pool_dedup_rows(self._h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
 
     def collect(self):
         """-> (uint8 feats [B,27,9,9] view, n_policy); B == 0 when every game is finished."""
@@ -260,6 +272,19 @@ class CallableEvaluator:
 
     def __call__(self, feats, n_policy):
         return self.finish(self.submit(feats, n_policy))
+
+
+class RecordEvaluator(CallableEvaluator):
+    """CallableEvaluator fed with position records (as the engine is: collect_positions): the planes are encoded on the host."""
+    wants_positions = True
+
+    def submit(self, recs, n_policy):
+        lib = go.golib()
+        r = np.ascontiguousarray(recs, np.uint8)
+        feats = np.empty((len(r), 27, 9, 9), np.uint8)
+        for i in range(len(r)):
+            lib.bk_pos_features_u8(ctypes.cast(r[i].ctypes.data, ctypes.POINTER(go.Pos)), feats[i].ctypes.data, 0)
+        return feats, n_policy
 
 
 def run_pools(pools, evaluator, progress=None):
@@ -374,6 +399,12 @@ def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None)
 # batches held to whole rounds of workgroups (task_cap below): fp32 3: 32.3 k | 4: 32.9 k | 5: 30.8 k | 6: 28.8 k | 8: 25.2 k;
 # f16x2 3: 55.4 k | 4: 58.9 k | 6: 62.6 k.
 EAGER_TOP = {"f32": 4, "f16x2": 6}
+# In-batch de-duplication of the pools' requests (bk_pool_set_dedup; the in-batch part of the reference's class-level memo,
+# mcts.py:41-44).  Measured on one MI355X, 512 games x 400 rollouts/move, the same games move for move (tools/dedup_ab.py,
+# profiles/r04_dedup.txt): 7.1 % of the rows are byte-for-byte repeats of another game's row in the same batch (all of them in
+# the first plies) -- fp32, which is GPU-bound, 33.2 k -> 34.6 k games/min (+4.2 %; 64 games: +2.0 %); f16x2, which is
+# host-bound, pays for the serial hashing with 81 k -> 55 k.  So: on for fp32, off for f16x2.  BK_DEDUP=0/1 overrides.
+DEDUP = {"f32": True, "f16x2": False}
 
 
 def shard_game_ids(n_games, rank, world):
@@ -382,7 +413,8 @@ def shard_game_ids(n_games, rank, world):
 
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
-              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None):
+              reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None,
+              dedup=None):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
@@ -411,8 +443,11 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         # two rounds -- rocprofv3 showed 605 of 1,160 launches at exactly 768 tasks taking the 1.0 ms three-round one-board form)
         per_round = 3 * getattr(getattr(evaluator, "engine", None), "n_cu", 256)
         task_cap = per_round * max(1, round(3.0 * max(len(part) for part in parts) / per_round)) - 4 if (precision == "f32" and eager_top) else 0
+    if dedup is None:
+        dedup = os.environ["BK_DEDUP"] == "1" if "BK_DEDUP" in os.environ else DEDUP.get(precision, False)
     for pool in pools:
         pool.set_task_cap(task_cap)
+        pool.set_dedup(dedup and getattr(evaluator, "wants_positions", False))
     t0 = time.perf_counter()
     steps = run_pools(pools, evaluator, progress)
     dt = time.perf_counter() - t0
@@ -423,13 +458,14 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
             if record_visits:
                 visits[g] = [pool.visits(i, ply) for ply in range(len(games[g]["moves"]))]
     local = pool_stats(pools) if pools else np.zeros(STATS_LEN)
+    rows_req, rows_sent = (sum(x) for x in zip(*[p.dedup_rows() for p in pools])) if pools else (0, 0)
     total, t_reduce = all_reduce_stats(local, reduce_device, native_comm)
     for p in pools:
         p.close()
     named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}
     named["first_move_hist"] = total[len(STATS_FIELDS):].astype(int).tolist()
     return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local,
-             "allreduce_s": t_reduce}, named)
+             "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
 
 
 # ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------

@@ -87,6 +87,7 @@ int main(int argc, char **argv) {
             if (!(pe2 && strcmp(pe2, "f16x2") == 0)) {
                 int rounds = (3 * k + 384) / 768;
                 bk_pool_set_task_cap(s[i].pool, 768 * (rounds < 1 ? 1 : rounds) - 4);
+                bk_pool_set_dedup(s[i].pool, 1);   /* equal records of one batch travel once: +4 % where the GPU is the limit */
             }
         }
         s[i].n_games = k;

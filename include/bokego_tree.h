@@ -111,6 +111,12 @@ void bk_pool_deliver(bk_pool *p, const float *probs, const float *values);
 /* host seconds this pool has spent so far advancing its games (select / expand / backup), writing request rows, and taking
  * deliveries: out3 = {advance, emit, deliver} (tools/selfplay_breakdown.py) */
 void bk_pool_phase_seconds(const bk_pool *p, double *out3);
+/* In-batch de-duplication for bk_pool_collect_pos (off by default): request rows of one batch whose 192-byte records are equal
+ * byte for byte -- games still in the same opening -- travel once and every asker gets the answer at deliver.  The reference
+ * keeps one memo for all trees (mcts.py:41-44); here a game has its own, and this is the part of the shared one that costs
+ * nothing to keep exact: the networks' outputs for equal records are the same bits.  Per-game counters do not change. */
+void bk_pool_set_dedup(bk_pool *p, int on);
+void bk_pool_dedup_rows(const bk_pool *p, uint64_t *requested, uint64_t *sent);
 /* stress of the worker threads the pools share (`jobs` short parallel regions on `threads` threads); 0 = every item ran once */
 int bk_team_selftest(int threads, int jobs);
 /* two callers at once, each with a region that waits (at most timeout_ms) to see the other's running: 0 = they ran side by side */
