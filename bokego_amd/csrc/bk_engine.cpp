@@ -1160,8 +1160,8 @@ int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* 
     double exe = 0.0;
     int launches = 0;
     if (n_policy + n_value > 0) {
-        if (cooperative && bk_coop_slices(n_policy + n_value, n_cu)) {
-            exe = bk_mfma_flop_per_workgroup(1) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
+        if (const int slices = cooperative ? bk_coop_slices(n_policy + n_value, n_cu) : 0) {
+            exe = bk_coop_mfma_flop_per_task(slices) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
             launches = 1;
         } else {
             const LaunchPlan pl = plan_launch(n_policy, n_value, n_cu, BK_PRECISION_F32);

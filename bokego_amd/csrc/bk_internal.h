@@ -86,6 +86,7 @@ hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStre
 int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision);
 long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision);  // modelled time of one launch (arbitrary units)
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
+double bk_coop_mfma_flop_per_task(int slices);   // ... of one task in the cooperative form with `slices` CUs per board
 double bk_mfma_flop_per_workgroup(int nb);   // fp32 kernel: executed MFMA FLOP of one net on one nb-board workgroup (tile tables)
 #define BK_COOP_MAX_TASKS 128
 #define BK_COOP_SYNC_STRIDE 64   // unsigned ints between two tasks' arrival counters

@@ -143,10 +143,11 @@ struct Tiles {
     static constexpr int CTW = 8 / WN;                  // 16-cout tiles per wave
     // tile classes of a wave: [A0, A1) always; X0 skips when dx < 0 resp. (NB == 3, wm == 1) dx > 0; X1 (NB == 2) when
     // dx > 0; [Y0a, Y0b) when dy < 0 resp. (NB == 3, wm == 1) dy > 0; Y1 (NB == 2) when dy > 0; -1: no such tile
-    // (1 board: 81 points in 6 tiles, too few per edge class to fill a tile: every tile runs every tap)
-    static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 6;
+    // 1 board (81 points, 6 tiles): [3 interior | x-edges + the 49th interior point | y=0 | y=8]: the two y-edge tiles (9 points
+    // + 7 padding rows each) skip their outward taps -- 48 of 54 tile-taps (round 3: the points in board order, nothing to skip)
+    static constexpr int A0 = NB == 3 ? 1 : NB == 2 ? 2 : 0, A1 = NB == 3 ? 6 : NB == 2 ? 9 : 4;
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
-    static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : -1, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : -1, Y1 = NB == 2 ? 10 : -1;
+    static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : 4, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : 5, Y1 = NB == 2 ? 10 : NB == 1 ? 5 : -1;
     static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
     static constexpr bool DB2 = NB != 3;                // second chain: double-buffered fragments too (conv_layer) where registers allow
 };
@@ -155,8 +156,16 @@ template <int NB>
 constexpr TileRow tile_row(int wm, int rt, int p16) {
     TileRow r{0, 4, 0, true};
     if constexpr (NB == 1) {
-        const int i = rt * 16 + p16;
-        if (i < 81) { r.y = i / 9; r.x = i % 9; } else r.valid = false;
+        if (rt <= 2) {                       // interior: the first 48 of the 49 points (y, x = 1..7)
+            const int i = rt * 16 + p16;
+            r.y = 1 + i / 7; r.x = 1 + i % 7;
+        } else if (rt == 3) {                // x = 0 and x = 8 (y = 1..7), the 49th interior point (7,7), one padding row
+            if (p16 < 14) { r.y = 1 + p16 % 7; r.x = p16 < 7 ? 0 : 8; }
+            else if (p16 == 14) { r.y = 7; r.x = 7; }
+            else r.valid = false;
+        } else {                             // y = 0 (tile 4) / y = 8 (tile 5): 9 points + 7 padding rows
+            if (p16 < 9) { r.y = rt == 4 ? 0 : 8; r.x = p16; } else r.valid = false;
+        }
     } else if constexpr (NB == 3) {
         if (rt == 0) {                       // x-edge tile: the first 16 of the 21 points (b, y = 1..7, x = 0 or 8)
             r.b = p16 / 7; r.y = 1 + p16 % 7; r.x = wm ? 8 : 0;
@@ -229,10 +238,12 @@ __device__ __forceinline__ int in_slot(int c) {
 // wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk); tile0: the wave's first cout tile.
 // ap[rt]: LDS address of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4); advanced tap by tap and put back at
 // the end (the kernel keeps ONE copy of these pointers alive across the layers).
-// W0..W3: the weight ring, owned by the kernel so that it lives across layers: the last two groups of a layer fetch
-// "the groups two ahead", i.e. the first two groups of the NEXT layer (the layers are contiguous in memory).
-// W0 / W1 hold this layer's groups 0 / 1 on entry.  On return the next layer's groups 0 / 1 sit in W2 / W3
-// after layer 0 (50 groups) and in W0 / W1 after a 3x3 layer (72 groups).
+// W0..W3: the weight ring, owned by the kernel so that it lives across layers: every group fetches "the group three ahead"
+// into the slot the group before it has just left; the last three groups of a layer so fetch the first three of the NEXT
+// layer (the layers are contiguous in memory).  W0 / W1 / W2 hold this layer's groups 0 / 1 / 2 on entry.  On return the
+// next layer's groups 0 / 1 / 2 sit in W2 / W3 / W0 after layer 0 (50 groups) and in W0 / W1 / W2 after a 3x3 layer (72).
+// (Two ahead until round 4: with one wave per SIMD and 8..12 MFMAs per group -- the cooperative forms once their y-edge tiles
+// skip taps -- two groups did not cover the L2 latency of the weights.)
 // F: the wave's tile set (Tiles<NB>, or CoopTiles<SC, SR, RH> of the cooperative small-batch kernel below).
 template <class F, bool FIRST>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[F::CTW][F::RT], int lane,
@@ -254,7 +265,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     // this wave's cout tiles (tile0 ..): 1 KiB per tile and group, 8 KiB per group
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + tile0 * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
-    int boff = 2 * 8192;                                // scalar: byte offset of the group being fetched
+    int boff = 3 * 8192;                                // scalar: byte offset of the group being fetched
     auto load_w = [&](f32x4 (&W)[CTW]) {
 #if BK_EXP & 2   // timing experiment (make exp EXP=2|3): no weight traffic in the loops -- results are wrong
         (void)W;
@@ -382,23 +393,24 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         // 3 boards: a wave's x-edge tile holds x = 0 (wm 0) or x = 8 (wm 1) points, its y-edge tiles y = 0 or y = 8
         const bool sx0 = F::WM_EDGES ? (wm == 0 ? lo_x : hi_x) : lo_x, sx1 = hi_x;
         const bool sy0 = F::WM_EDGES ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
+        // group n of the layer uses ring slot n % 4 and fetches group n + 3 into slot (n + 3) % 4, which group n - 1 has left
         if constexpr (FIRST) {
             if constexpr (decltype(PHc)::value == 0) {
-                do_group(DBc, I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
-                do_group(DBc, I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I0{}, W0, W3, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I1{}, W1, W0, d, sx0, sx1, sy0, sy1);
             } else {
-                do_group(DBc, I0{}, W2, W0, d, sx0, sx1, sy0, sy1);
-                do_group(DBc, I1{}, W3, W1, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I0{}, W2, W1, d, sx0, sx1, sy0, sy1);
+                do_group(DBc, I1{}, W3, W2, d, sx0, sx1, sy0, sy1);
             }
         } else {
-            do_group(DBc, I0{}, W0, W2, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I1{}, W1, W3, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I2{}, W2, W0, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I3{}, W3, W1, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I4{}, W0, W2, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I5{}, W1, W3, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I6{}, W2, W0, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I7{}, W3, W1, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I0{}, W0, W3, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I1{}, W1, W0, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I2{}, W2, W1, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I3{}, W3, W2, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I4{}, W0, W3, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I5{}, W1, W0, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I6{}, W2, W1, d, sx0, sx1, sy0, sy1);
+            do_group(DBc, I7{}, W3, W2, d, sx0, sx1, sy0, sy1);
         }
     };
 
@@ -630,6 +642,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         for (int ct = 0; ct < F::CTW; ++ct) {
             Wr0[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 0, 0));
             Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
+            Wr2[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 16384, 0));
         }
     }
     stage_input<NB, G::THREADS>(a, actb, b0, nb, tid);
@@ -734,8 +747,29 @@ struct CoopTiles {
     static constexpr int S = SC * SR;                   // workgroups per board
     static constexpr int ROWT = 6 / SR;                 // position tiles per workgroup
     static constexpr int RT = ROWT / RH, CTW = 1;
-    static constexpr int A0 = 0, A1 = RT, X0 = -1, X1 = -1, Y0a = -1, Y0b = -1, Y1 = -1;
-    static constexpr bool WM_EDGES = false, DB2 = true;
+    // The one-board tile set (tile_row<1>: tiles 0..2 interior, 3 x-edges, 4 y = 0, 5 y = 8) dealt out to the waves:
+    //   SR == 1, RH == 2 (the 4x1 and 2x1 forms, 33..64 and 81..128 tasks): row group 0 = tiles {0, 1, 4}, row group 1 =
+    //       {2, 3, 5} -- two tiles that run every tap and one y-edge tile that skips its outward taps (the row group plays
+    //       the part `wm` plays for 3-board workgroups): 24 instead of 27 tile-taps per wave and 3x3 layer;
+    //   every other form: no wave could get shorter by skipping (RH == 6: one tile per wave, the slowest decides; SR == 3:
+    //       three workgroups of two tiles, one of them holds two interior tiles): tiles in the order of TILE below, every tap.
+    static constexpr bool SKIP = SR == 1 && RH == 2;
+    static constexpr int A0 = 0, A1 = SKIP ? 2 : RT, X0 = -1, X1 = -1, Y0a = SKIP ? 2 : -1, Y0b = SKIP ? 3 : -1, Y1 = -1;
+    static constexpr bool WM_EDGES = SKIP, DB2 = true;
+    // canonical tile of the workgroup's k-th tile (k = rh * RT + rt) in point range sr
+    static constexpr int tile(int sr, int k) {
+        constexpr int PAIRS[6] = {0, 1, 2, 4, 3, 5};    // SR == 3: {0,1} {2,4} {3,5}
+        constexpr int HALVES[6] = {0, 1, 4, 2, 3, 5};   // SR == 1, RH == 2
+        return SKIP ? HALVES[k] : SR == 3 ? PAIRS[2 * sr + k] : k;
+    }
+    // which point range (SR == 3) computes board point q
+    static constexpr int owner(int q) {
+        const int y = q / 9, x = q - 9 * y;
+        const int i = (y - 1) * 7 + (x - 1);
+        const int t = y == 0 ? 4 : y == 8 ? 5 : (x == 0 || x == 8 || i >= 48) ? 3 : i / 16;
+        constexpr int SR_OF[6] = {0, 0, 1, 2, 1, 2};
+        return SR == 3 ? SR_OF[t] : 0;
+    }
     static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = CT * RH, THREADS = 64 * NW;
     static constexpr int XCHG_FLOATS = 2 * 81 * 128;    // per task: two layer parities
@@ -773,6 +807,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
         Wr0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 0, 0));
         Wr1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 8192, 0));
+        Wr2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 16384, 0));
     }
     if (tid == 0) {
         // an earlier launch of this engine timed out and the host has not cleared the counters yet: do not trust them
@@ -791,7 +826,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
     int storea[RT], xoff[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const TileRow fr = tile_row<1>(0, sr * F::ROWT + rh * RT + rt, lane & 15);
+        const TileRow fr = tile_row<1>(0, F::tile(sr, rh * RT + rt), lane & 15);
         ap0[rt] = (lds_cchar*)actb + (G::addr0(0, fr.y, fr.x) - 2 * RP0 - 2 * REC0 + kq * 16);
         ap3[rt] = (lds_cchar*)actb + (G::addr3(0, fr.y, fr.x) - RP3 - REC3 + kq * 16);
         storea[rt] = fr.valid ? G::addr3(0, fr.y, fr.x) + (16 * wn + 4 * kq) * 4 : dummy_byte;
@@ -799,6 +834,18 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
     }
     f32x4 bv[1];
 
+    // which of this thread's chunks of the exchange (chunk i = tid + THREADS k: point i / 32, channels 4 (i % 32) ..) another
+    // workgroup computes: the same in every layer
+    unsigned foreign_mask = 0;
+    {
+        constexpr int OWN = 32 / SC, PER = (81 * 32 + THREADS - 1) / THREADS;
+        static_assert(PER <= 32, "one bit per chunk");
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + THREADS * k;
+            if (i < 81 * 32 && !(((i & 31) / OWN) == sc && F::owner(i >> 5) == sr)) foreign_mask |= 1u << k;
+        }
+    }
     // own slice: LDS + exchange buffer; then meet the peers and fetch theirs.  After the last layer only slice 0 goes on.
     // Coherence without cache-wide fences (a buffer_wbl2 / buffer_inv per wave and layer cost more than the convolutions
     // once 30 groups shared an L2): the slices are written and read with device-scope (sc1) accesses, a wave waits for
@@ -843,8 +890,8 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
         __syncthreads();
         STAMP(4 + 4 * L);
         // the peers' slices: every 16-byte chunk (point q, channels 4c..4c+3) this workgroup did not compute itself
-        constexpr int OWN = 32 / SC, PER = (81 * 32 + THREADS - 1) / THREADS;
-        auto foreign = [&](int i) { return i < 81 * 32 && !(((i & 31) / OWN) == sc && ((i >> 5) >> 4) / F::ROWT == sr); };
+        constexpr int PER = (81 * 32 + THREADS - 1) / THREADS;
+        auto foreign = [&](int i) { return (foreign_mask >> ((i - tid) / THREADS)) & 1u; };
         f32x4 v[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -866,7 +913,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 
     // ---- layer 0: 5x5, 27 -> 128 ----
     load_bias<F>(bv, P.bias, wn, kq);
-    conv_layer<F, true>(actb, P.wfrag, acc, lane, 0, wn, ap0, Wr0, Wr1, Wr2, Wr3);
+    conv_layer<F, true>(actb, P.wfrag, acc, lane, rh, wn, ap0, Wr0, Wr1, Wr2, Wr3);
     STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::L3_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -876,7 +923,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
-        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, 0, wn, ap3, Wr2, Wr3, Wr0, Wr1);
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, rh, wn, ap3, Wr2, Wr3, Wr0, Wr1);
         STAMP(2 + 4 * L);
         __syncthreads();
         if (!exchange(L)) return;
@@ -941,7 +988,7 @@ constexpr long tile_taps(int kw) {
     return (long)(F::A1 - F::A0) * taps + (long)(nx + ny) * (taps - skip);
 }
 static_assert(tile_taps<Tiles<3>>(3) == 63 && tile_taps<Tiles<3>>(5) == 170, "3 boards: 63 of 72 / 170 of 200 tile-taps");
-static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 54, "2 boards: 87 of 99; 1 board: all 54");
+static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 48 && tile_taps<Tiles<1>>(5) == 130, "2 boards: 87 of 99; 1 board: 48 of 54");
 // FLOP the matrix unit executes for ONE net on one NB-board workgroup: per (tile, tap) 7 k-steps in layer 0 (28 input
 // slots) resp. 32 in a 3x3 layer, x 8 cout tiles, of v_mfma_f32_16x16x4_f32 (2 * 16 * 16 * 4 = 2,048 FLOP each)
 template <int NB>
@@ -949,10 +996,18 @@ constexpr double mfma_flop_workgroup() {
     using F = Tiles<NB>;
     return 2048.0 * 8 * F::WM * (double)(tile_taps<F>(5) * 7 + 6 * tile_taps<F>(3) * 32);
 }
-// the cooperative form deals the one-board tile set (6 position tiles x 8 cout tiles, no edge classes) out to its slices
-static_assert(CoopTiles<4, 1, 2>::X0 < 0 && CoopTiles<4, 1, 2>::Y0a < 0 && CoopTiles<1, 3, 1>::ROWT * 3 == Tiles<1>::RT, "coop = 1-board tiles");
+// the cooperative forms deal the one-board tile set (6 position tiles x 8 cout tiles) out to their slices: with the y-edge
+// tiles' outward taps skipped (SKIP: as the one-CU form) or every tap of every tile
+static_assert(2 * tile_taps<CoopTiles<4, 1, 2>>(3) == tile_taps<Tiles<1>>(3) && CoopTiles<1, 3, 1>::ROWT * 3 == Tiles<1>::RT, "coop = 1-board tiles");
+constexpr double coop_flop_task(bool skip) {
+    return skip ? mfma_flop_workgroup<1>() : 2048.0 * 8 * (double)(6 * 25 * 7 + 6 * 6 * 9 * 32);
+}
 
 }  // namespace
+
+double bk_coop_mfma_flop_per_task(int slices) {          // executed MFMA FLOP of one (net, board) task in the cooperative form
+    return coop_flop_task(slices == 4 || slices == 2);
+}
 
 double bk_mfma_flop_per_workgroup(int nb) {
     return nb == 3 ? mfma_flop_workgroup<3>() : nb == 2 ? mfma_flop_workgroup<2>() : mfma_flop_workgroup<1>();

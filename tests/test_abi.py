@@ -50,8 +50,11 @@ def test_plan_flops_counts_the_tile_tables(lib):
     assert nl == 2 and al == 4096 * 266838272
     assert ex == 2560 * 435355648 + 256 * 2048 * 8 * (235 * 7 + 6 * 87 * 32)
     assert 1.05 < ex / al < 1.10
-    one = 2048 * 8 * 6 * (25 * 7 + 6 * 9 * 32)              # a single board: 6 tiles, every tap
-    assert q(1, 62, coop=1) == (63 * one, 2.0 * (66706944 + 62 * 66712192), 1) == q(1, 62, coop=0)
+    one = 2048 * 8 * (130 * 7 + 6 * 48 * 32)                # a single board: 6 tiles, the two y-edge tiles skip their outward taps
+    every = 2048 * 8 * 6 * (25 * 7 + 6 * 9 * 32)            # ... every tap of every tile (round 3; still the 3-, 8- and 12-CU cooperative forms)
+    assert q(1, 62, coop=1) == (63 * one, 2.0 * (66706944 + 62 * 66712192), 1) == q(1, 62, coop=0)     # 63 tasks: 4 CUs per board
+    assert q(1, 70, coop=1)[0] == 71 * every and q(1, 70, coop=0)[0] == 71 * one                       # 71 tasks: 3 CUs per board
+    assert one / every < 0.9
     assert q(0, 0) == (0.0, 0.0, 0) and lib.bk_plan_flops(-1, 0, 256, 0, None, None, None) == -1
     assert lib.bk_plan_flops(5, 5, 256, 0, None, None, None) == 0   # every out pointer may be NULL
 
