@@ -275,9 +275,24 @@ class NativeMCTS:
         return mv[:max(n, 0)].tolist()
 
     def choose(self, node=None):
-        """Most visited child of the root becomes the new root (mcts.py:110-131)."""
+        """Most visited child of the root becomes the new root; `node`: choose from another node of the tree -- the best
+        child is returned and the root stays where it is (mcts.py:110-131)."""
         if node is not None and node.key() != self.root.key():
-            raise NotImplementedError("NativeMCTS.choose works at the root")
+            if getattr(node, "_terminal", False):
+                return node
+            i = self._find(node)
+            kids = self._children_ids(i) if i >= 0 and self._node_at(i).flags & 1 else []
+            if not kids:
+                # not expanded (`node not in self.children`): the reference samples a child from the node's policy,
+                # mcts.py:119-120 -- Position.find_random_child does that, through this tree's evaluator
+                return self._sample_child(self._position(i) if i >= 0 else node)
+            best, best_n = None, None
+            for c in kids:                     # most visited, unseen children last; first in move order on ties
+                cn = self._node_at(c).N
+                sc = float("-inf") if cn == 0 else cn
+                if best is None or sc > best_n:
+                    best, best_n = c, sc
+            return self._position(best)
         r = self.root
         if r._terminal:
             return r
@@ -286,6 +301,40 @@ class NativeMCTS:
             self.play(go.PASS)
         self._pump()
         return self.root
+
+    def _sample_child(self, node):
+        """Go_MCTS.find_random_child (mcts.py:337-360) for a node of this tree: a legal, non-eye-filling move sampled from the
+        node's policy -- the tree's prior where it has one, else one evaluation through the tree's evaluator -- passing as
+        the last resort."""
+        import torch
+        if getattr(node, "_terminal", False):
+            return node
+        d = self._dist(node)
+        if d is None:
+            planes = node.features_u8()                  # (refreshes the liberty cache, as the search's requests do)
+            if getattr(self.evaluator, "wants_positions", False):
+                rows = np.frombuffer(bytes(node._pos), np.uint8).reshape(1, 192).copy()
+            else:
+                rows = planes[None]
+            probs, _ = self.evaluator(rows, 1)
+            pr = torch.from_numpy(np.asarray(probs[0], np.float32))
+        else:
+            pr = d.probs.clone()                         # (the tree's own prior is left alone)
+        d = torch.distributions.Categorical(probs=pr, validate_args=False)
+        d.probs = pr
+        color = 1 if node.turn % 2 == 0 else 2
+        move, tries = d.sample().item(), 0
+        while not node.is_legal(move) or go.golib().bk_pos_eye_like(ctypes.byref(node._pos), move, color):
+            d.probs[move] = 0                            # as the reference: a rejected move is not drawn again
+            if tries >= go.N ** 2 or not float(d.probs.sum()) > 0:
+                move = go.PASS
+                break
+            move, tries = d.sample().item(), tries + 1
+        child = node.copy()
+        child.tree = self
+        child.play_pass() if move == go.PASS else child.play_move(move)
+        child._terminal = child.is_game_over()
+        return child
 
     def play(self, move):
         """An outside move: the root's child for `move` (created if needed) becomes the root."""
