@@ -9,7 +9,7 @@
 #define BK_L0_FLOATS (25 * 2 * 2048)
 #define BK_L3_FLOATS (9 * 8 * 2048)
 #define BK_WFRAG_FLOATS (BK_L0_FLOATS + 6 * BK_L3_FLOATS)
-#define BK_WFRAG_PAD_FLOATS 8192  // the weight prefetch runs up to 32 KiB past the last layer (3 groups of 8 KiB)
+#define BK_WFRAG_PAD_FLOATS 16384  // the weight prefetch runs up to 64 KiB past the last layer (7 groups of 8 KiB, + a wave's offset)
 
 // f16x2 path: per layer [k16 step][cout tile (4)][piece hi/lo][lane (64)][8 halfs] = 4096 halfs per step
 #define BK16_L0_STEPS 52                      // 25 taps x 2 steps, zero-padded to a multiple of 4

@@ -150,6 +150,7 @@ struct Tiles {
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : 4, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : 5, Y1 = NB == 2 ? 10 : NB == 1 ? 5 : -1;
     static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
     static constexpr bool DB2 = NB != 3;                // second chain: double-buffered fragments too (conv_layer) where registers allow
+    static constexpr int RING = 4;                      // slots of the weight ring (groups fetched RING - 1 ahead)
 };
 struct TileRow { int b, y, x; bool valid; };
 template <int NB>
@@ -238,18 +239,20 @@ __device__ __forceinline__ int in_slot(int c) {
 // wl: the layer's weights [tap][group of 16 input slots][cout tile (8)][lane][4] (pack_trunk); tile0: the wave's first cout tile.
 // ap[rt]: LDS address of this lane's position of tile rt at tap (0,0), + 16 * (lane >> 4); advanced tap by tap and put back at
 // the end (the kernel keeps ONE copy of these pointers alive across the layers).
-// W0..W3: the weight ring, owned by the kernel so that it lives across layers: every group fetches "the group three ahead"
-// into the slot the group before it has just left; the last three groups of a layer so fetch the first three of the NEXT
-// layer (the layers are contiguous in memory).  W0 / W1 / W2 hold this layer's groups 0 / 1 / 2 on entry.  On return the
-// next layer's groups 0 / 1 / 2 sit in W2 / W3 / W0 after layer 0 (50 groups) and in W0 / W1 / W2 after a 3x3 layer (72).
-// (Two ahead until round 4: with one wave per SIMD and 8..12 MFMAs per group -- the cooperative forms once their y-edge tiles
-// skip taps -- two groups did not cover the L2 latency of the weights.)
+// W: the weight ring of F::RING slots, owned by the kernel so that it lives across layers: group n of the network's stream uses
+// slot n % RING and fetches group n + RING - 1 into the slot the group before it has just left; the last groups of a layer so
+// fetch the first ones of the NEXT layer (the layers are contiguous in memory).  Layer 0 starts at slot 0, its 50 groups leave
+// the 3x3 layers (72 groups each: a whole number of turns) at slot 2.  RING = 4: three groups ahead (two until round 4: with
+// one wave per SIMD and 4..12 MFMAs per group -- the cooperative forms -- two groups did not cover the L2 latency of the
+// weights: 8 CUs per board 100 -> 85 us).  Eight slots, seven ahead, were measured too (the code takes RING = 8): no further
+// gain in any form (86.9 against 84.9 us at 9 tasks, 104.1 against 103.5 at 63, 141.6 against 134.7 at 65) -- three cover it.
 // F: the wave's tile set (Tiles<NB>, or CoopTiles<SC, SR, RH> of the cooperative small-batch kernel below).
 template <class F, bool FIRST>
 __device__ __forceinline__ void conv_layer(const char* actb, const float* __restrict__ wl, f32x4 (&acc)[F::CTW][F::RT], int lane,
-                                           int wm, int tile0, lds_cchar* (&ap)[F::RT], f32x4 (&W0)[F::CTW],
-                                           f32x4 (&W1)[F::CTW], f32x4 (&W2)[F::CTW], f32x4 (&W3)[F::CTW]) {
-    constexpr int RT = F::RT, CTW = F::CTW;
+                                           int wm, int tile0, lds_cchar* (&ap)[F::RT], f32x4 (&W)[F::RING][F::CTW]) {
+    constexpr int RT = F::RT, CTW = F::CTW, RING = F::RING;
+    static_assert(RING == 4 || RING == 8, "layer 0's 50 groups leave the ring at slot 2: what the 3x3 layers start from");
+    constexpr int PH = FIRST ? 0 : 50 % RING;           // ring slot of the layer's group 0
     constexpr int KW = FIRST ? 5 : 3, TAPS = KW * KW;
     constexpr int HALF = FIRST ? 12 : 5;                // the second chain starts at this tap (layer 0: even, its taps go in pairs)
     constexpr int G = FIRST ? 2 : 8;                    // groups of 16 input slots per tap
@@ -265,7 +268,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     // this wave's cout tiles (tile0 ..): 1 KiB per tile and group, 8 KiB per group
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wl + tile0 * 256), 0, 0x7ffffff0, 0x00020000);
     const int lane16 = lane * 16;
-    int boff = 3 * 8192;                                // scalar: byte offset of the group being fetched
+    int boff = (RING - 1) * 8192;                       // scalar: byte offset of the group being fetched
     auto load_w = [&](f32x4 (&W)[CTW]) {
 #if BK_EXP & 2   // timing experiment (make exp EXP=2|3): no weight traffic in the loops -- results are wrong
         (void)W;
@@ -385,7 +388,7 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
     using I5 = std::integral_constant<int, 5>;
     using I6 = std::integral_constant<int, 6>;
     using I7 = std::integral_constant<int, 7>;
-    // one tap; DB: first chain; PH: ring slot of the tap's first group (0, or 2 for layer 0's odd taps)
+    // one tap; DB: first chain; PHc: ring slot of the tap's first group
     auto tap = [&](auto DBc, auto PHc, int t) {
         const int ky = t / KW, kx = t - ky * KW;
         const int d = t == TAPS - 1 ? 0 : (kx == KW - 1 ? RP - (KW - 1) * REC : REC);
@@ -393,40 +396,48 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         // 3 boards: a wave's x-edge tile holds x = 0 (wm 0) or x = 8 (wm 1) points, its y-edge tiles y = 0 or y = 8
         const bool sx0 = F::WM_EDGES ? (wm == 0 ? lo_x : hi_x) : lo_x, sx1 = hi_x;
         const bool sy0 = F::WM_EDGES ? (wm == 0 ? lo_y : hi_y) : lo_y, sy1 = hi_y;
-        // group n of the layer uses ring slot n % 4 and fetches group n + 3 into slot (n + 3) % 4, which group n - 1 has left
-        if constexpr (FIRST) {
-            if constexpr (decltype(PHc)::value == 0) {
-                do_group(DBc, I0{}, W0, W3, d, sx0, sx1, sy0, sy1);
-                do_group(DBc, I1{}, W1, W0, d, sx0, sx1, sy0, sy1);
-            } else {
-                do_group(DBc, I0{}, W2, W1, d, sx0, sx1, sy0, sy1);
-                do_group(DBc, I1{}, W3, W2, d, sx0, sx1, sy0, sy1);
-            }
-        } else {
-            do_group(DBc, I0{}, W0, W3, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I1{}, W1, W0, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I2{}, W2, W1, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I3{}, W3, W2, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I4{}, W0, W3, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I5{}, W1, W0, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I6{}, W2, W1, d, sx0, sx1, sy0, sy1);
-            do_group(DBc, I7{}, W3, W2, d, sx0, sx1, sy0, sy1);
+        // group n of the layer (ring slot (PH + n) % RING) fetches group n + RING - 1 into the slot group n - 1 has left
+        constexpr int P0 = decltype(PHc)::value;        // slot of this tap's group 0
+        auto grp = [&](auto GIc) {
+            constexpr int g = decltype(GIc)::value;
+            do_group(DBc, GIc, W[(P0 + g) % RING], W[(P0 + g + RING - 1) % RING], d, sx0, sx1, sy0, sy1);
+        };
+        grp(I0{});
+        grp(I1{});
+        if constexpr (!FIRST) {
+            grp(I2{});
+            grp(I3{});
+            grp(I4{});
+            grp(I5{});
+            grp(I6{});
+            grp(I7{});
         }
     };
 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) read_a(A0[rt], rt, 0);
-    // first chain: taps [0, HALF), an even number of groups: the second chain finds its first fragments in A0
-    if constexpr (FIRST) {
+    // taps [t0, t1) of one chain.  3x3: every tap starts at slot PH (8 groups per tap = whole turns of the ring).  Layer 0 (2
+    // groups per tap): RING / 2 taps make a turn, so the loop is unrolled that far; t0 and t1 are multiples of it here
+    auto taps = [&](auto DBc, int t0, int t1) {
+        if constexpr (FIRST) {
+            constexpr int U = RING / 2;
 #pragma unroll 1
-        for (int t = 0; t < HALF; t += 2) {
-            tap(std::true_type{}, I0{}, t);
-            tap(std::true_type{}, I2{}, t + 1);
+            for (int t = t0; t < t1; t += U) {
+                tap(DBc, std::integral_constant<int, 0>{}, t);
+                tap(DBc, std::integral_constant<int, 2>{}, t + 1);
+                if constexpr (U == 4) {
+                    tap(DBc, std::integral_constant<int, 4>{}, t + 2);
+                    tap(DBc, std::integral_constant<int, 6>{}, t + 3);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int t = t0; t < t1; ++t) tap(DBc, std::integral_constant<int, PH>{}, t);
         }
-    } else {
-#pragma unroll 1
-        for (int t = 0; t < HALF; ++t) tap(std::true_type{}, I0{}, t);
-    }
+    };
+    static_assert(!FIRST || (HALF % (RING / 2) == 0 && (TAPS - 1) % (RING / 2) == 0), "layer 0: 12 + 12 taps in whole turns, then tap 24 at slot 0");
+    // first chain: taps [0, HALF), an even number of groups: the second chain finds its first fragments in A0
+    taps(std::true_type{}, 0, HALF);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -436,17 +447,8 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
         }
     // second chain: taps [HALF, TAPS)
     using DB2 = std::integral_constant<bool, F::DB2>;
-    if constexpr (FIRST) {
-#pragma unroll 1
-        for (int t = HALF; t < TAPS - 1; t += 2) {
-            tap(DB2{}, I0{}, t);
-            tap(DB2{}, I2{}, t + 1);
-        }
-        tap(DB2{}, I0{}, TAPS - 1);
-    } else {
-#pragma unroll 1
-        for (int t = HALF; t < TAPS; ++t) tap(DB2{}, I0{}, t);
-    }
+    taps(DB2{}, HALF, FIRST ? TAPS - 1 : TAPS);
+    if constexpr (FIRST) tap(DB2{}, std::integral_constant<int, 0>{}, TAPS - 1);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         ap[rt] -= (KW - 1) * (RP + REC);                // back to tap (0,0): the taps advanced it by KW - 1 rows and KW - 1 columns
@@ -635,15 +637,14 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // wave grid and the weight ring (see conv_layer); layer 0's first two channel groups are requested before the staging
     using F = Tiles<NB>;
     const int wm = wave / F::WN, wn = wave - wm * F::WN;
-    f32x4 Wr0[F::CTW], Wr1[F::CTW], Wr2[F::CTW], Wr3[F::CTW];
+    f32x4 Wr[F::RING][F::CTW];
     {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * F::CTW * 256), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-        for (int ct = 0; ct < F::CTW; ++ct) {
-            Wr0[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 0, 0));
-            Wr1[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 8192, 0));
-            Wr2[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, 16384, 0));
-        }
+        for (int n = 0; n < F::RING - 1; ++n)
+#pragma unroll
+            for (int ct = 0; ct < F::CTW; ++ct)
+                Wr[n][ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16 + ct * 1024, n * 8192, 0));
     }
     stage_input<NB, G::THREADS>(a, actb, b0, nb, tid);
     __syncthreads();
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
         lds_cchar* ap0[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) ap0[rt] = (lds_cchar*)actb + (g_rows<NB>.a0[row_i + rt * 16] + kq * 16);
-        conv_layer<F, true>(actb, P.wfrag, acc, lane, wm, wn * F::CTW, ap0, Wr0, Wr1, Wr2, Wr3);
+        conv_layer<F, true>(actb, P.wfrag, acc, lane, wm, wn * F::CTW, ap0, Wr);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {                   // (fetched now rather than kept alive through layer 0)
@@ -698,7 +699,7 @@ __global__ void __launch_bounds__(Geo<NB>::THREADS) bk_leaf_eval_kernel(const bk
     // ---- layers 1..6: 3x3, 128 -> 128, in place ----
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
-        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn * F::CTW, ap3, Wr2, Wr3, Wr0, Wr1);
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn * F::CTW, ap3, Wr);
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
         STAMP(2 + 4 * L);
         __syncthreads();
@@ -756,6 +757,7 @@ struct CoopTiles {
     static constexpr bool SKIP = SR == 1 && RH == 2;
     static constexpr int A0 = 0, A1 = SKIP ? 2 : RT, X0 = -1, X1 = -1, Y0a = SKIP ? 2 : -1, Y0b = SKIP ? 3 : -1, Y1 = -1;
     static constexpr bool WM_EDGES = SKIP, DB2 = true;
+    static constexpr int RING = 4;
     // canonical tile of the workgroup's k-th tile (k = rh * RT + rt) in point range sr
     static constexpr int tile(int sr, int k) {
         constexpr int PAIRS[6] = {0, 1, 2, 4, 3, 5};    // SR == 3: {0,1} {2,4} {3,5}
@@ -802,12 +804,12 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
     const int sc = slice % SC, sr = slice / SC;         // this workgroup's cout range and point range
     const int wc = wave / RH, rh = wave - wc * RH;
     const int wn = sc * F::CT + wc;                     // this wave's cout tile (of 8)
-    f32x4 Wr0[1], Wr1[1], Wr2[1], Wr3[1];
+    f32x4 Wr[F::RING][1];
     {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
-        Wr0[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 0, 0));
-        Wr1[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 8192, 0));
-        Wr2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, 16384, 0));
+#pragma unroll
+        for (int n = 0; n < F::RING - 1; ++n)
+            Wr[n][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, n * 8192, 0));
     }
     if (tid == 0) {
         // an earlier launch of this engine timed out and the host has not cleared the counters yet: do not trust them
@@ -913,7 +915,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 
     // ---- layer 0: 5x5, 27 -> 128 ----
     load_bias<F>(bv, P.bias, wn, kq);
-    conv_layer<F, true>(actb, P.wfrag, acc, lane, rh, wn, ap0, Wr0, Wr1, Wr2, Wr3);
+    conv_layer<F, true>(actb, P.wfrag, acc, lane, rh, wn, ap0, Wr);
     STAMP(2);
     __syncthreads();
     for (int i = tid; i < G::L3_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -923,7 +925,7 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
-        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, rh, wn, ap3, Wr2, Wr3, Wr0, Wr1);
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, rh, wn, ap3, Wr);
         STAMP(2 + 4 * L);
         __syncthreads();
         if (!exchange(L)) return;

@@ -240,3 +240,26 @@ def test_worker_team_on_the_gpu_host():
     lib = selfplay.treelib()
     for threads in (2, 3, 6, 12):
         assert lib.bk_team_selftest(threads, 300_000) == 0
+
+
+def test_in_batch_deduplication_on_the_engine_plays_the_same_games():
+    """bk_pool_set_dedup on the real path (fp32 engine, planes encoded on the GPU from the records that travel): 128 games x 400
+    rollouts/move with and without it -- the same games move for move, the same per-game evaluation counts, fewer rows sent; and
+    the default follows the engine's precision (on for fp32, off for f16x2)."""
+    from bokego_amd.engine import LeafEngine
+    eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=8192)
+    ev = selfplay.EngineEvaluator(eng)
+    runs = {}
+    for name, dd in (("plain", False), ("dedup", True), ("default", None)):
+        local, total = selfplay.self_play(ev, n_games=128, rollouts=400, cap=8192, dedup=dd)
+        runs[name] = (local, total)
+    base = runs["plain"]
+    for name in ("dedup", "default"):
+        local, total = runs[name]
+        assert local["games"] == base[0]["games"] and total == base[1]
+        assert local["dedup"] and 0 < local["rows_sent"] < local["rows_requested"]
+    assert not base[0]["dedup"] and base[0]["rows_requested"] == 0
+    eng.set_precision("f16x2")
+    local, _ = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=16, rollouts=50, cap=8192)
+    assert not local["dedup"]
+    eng.close()
