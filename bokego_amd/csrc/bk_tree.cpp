@@ -194,13 +194,36 @@ struct Game {
         return w;
     }
 
+    // branch_num (mcts.py:189-190, 309-317): the node's children are the legal moves among the k best-prior moves
+    bool branching() const { return prm.branch_num > 0 && prm.branch_num < 81; }
+    int pending_expand = -1;      // a node whose expansion waits for its policy (branch_num)
+
     // mcts.py:185-192 + the eager evaluation of the new children
     void expand(int id) {
         if (nodes[id].expanded) return;
+        if (branching() && !nodes[id].terminal && !nodes[id].has_prior) {
+            // which moves become children depends on the priors: ask for them, expand when they are back (finish_expand)
+            auto queued = std::find(req_policy.begin(), req_policy.end(), id) != req_policy.end();
+            if (!queued) req_policy.push_back(id);
+            pending_expand = id;
+            return;
+        }
         bk_pos kids[81];
         int16_t mv[81];
         int n = 0;
         if (!nodes[id].terminal) n = bk_pos_children(&poses[id], kids, mv);
+        if (branching() && n > 0) {
+            const double* pr = &priors[nodes[id].prior_off];
+            int order[81];
+            for (int i = 0; i < 81; ++i) order[i] = i;
+            std::stable_sort(order, order + 81, [&](int a, int b) { return pr[a] > pr[b]; });
+            bool top[81] = {false};
+            for (int i = 0; i < prm.branch_num; ++i) top[order[i]] = true;
+            int m = 0;
+            for (int i = 0; i < n; ++i)
+                if (mv[i] >= 0 && mv[i] < 81 && top[mv[i]]) { kids[m] = kids[i]; mv[m] = mv[i]; ++m; }
+            n = m;
+        }
         const int off = (int)kid_ids.size();
         for (int i = 0; i < n; ++i) kid_ids.push_back(intern(kids[i]));  // may reallocate `nodes`
         TNode& nd = nodes[id];
@@ -476,6 +499,15 @@ struct Game {
                     }
                     break;
                 case S_WAIT_ROOT:
+                    if (pending_expand >= 0) {                       // branch_num: the root's priors are in
+                        const int id = pending_expand;
+                        pending_expand = -1;
+                        expand(id);
+                        if (has_request()) {                         // its best children's values (eager)
+                            add_speculation();
+                            return true;
+                        }
+                    }
                     state = S_ROOT_READY;
                     break;
                 case S_ROOT_READY:
@@ -521,6 +553,11 @@ struct Game {
                     break;
                 }
                 case S_WAIT_LEAF:
+                    if (pending_expand >= 0) {                       // branch_num: the leaf's priors are in: expand it before
+                        const int id = pending_expand;               // the next rollout (what it asks for rides with a later request)
+                        pending_expand = -1;
+                        expand(id);
+                    }
                     backprop();
                     --remaining;
                     state = S_SEARCH;
@@ -604,6 +641,7 @@ void bk_search_params_default(bk_search_params* p) {
     p->speculate_rows = 128;
     p->request_tasks = 0;
     p->request_steps[0] = p->request_steps[1] = p->request_steps[2] = 0;
+    p->branch_num = 0;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {

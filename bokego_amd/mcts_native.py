@@ -132,10 +132,9 @@ class NativeMCTS:
             raise NotImplementedError("NativeMCTS implements the no-simulation mode only")
         if value_net is None and kwargs.get("evaluator") is None:
             raise TypeError("Keyword argument 'value_net' is required for no simulation mode")
-        if kwargs.get("branch_num"):
-            # mcts.py:189-190 (children = the legal moves among the policy's top k): the native tree expands every legal move;
-            # the Python tree (bokego_amd.mcts.MCTS) implements the restriction
-            raise NotImplementedError("NativeMCTS does not implement branch_num; use bokego_amd.mcts.MCTS")
+        # mcts.py:62,189-190: children = the legal moves among the policy's top k (bk_search_params.branch_num: an expansion then
+        # waits for the node's priors).  None / 0 / >= 81: every legal move.
+        self.branch_num = kwargs.get("branch_num")
         self.policy_net, self.value_net = policy_net, value_net
         self.expand_thresh = kwargs.get("expand_thresh", 100)
         self.exploration_weight = kwargs.get("exploration_weight", 4.0)
@@ -166,6 +165,10 @@ class NativeMCTS:
                                      speculate=spec[0], speculate_rows=spec[1], request_tasks=spec[2],
                                      request_steps=kwargs.get("request_steps", (spec[2], 80, 128) if spec[2] == 64 else (spec[2],)))
         prm.eager_top = kwargs.get("eager_top", EAGER_TOP)
+        if self.branch_num is not None and 0 <= self.branch_num < go.N ** 2:
+            if self.branch_num == 0:
+                raise NotImplementedError("branch_num = 0 (no children at all) is not a search; use bokego_amd.mcts.MCTS to reproduce it")
+            prm.branch_num = int(self.branch_num)
         self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=kwargs.get("cap", 1024), threads=1)
         self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, None)   # Q: simulations are off
         self.children = _ChildrenView(self)

@@ -31,7 +31,7 @@ class SearchParams(ctypes.Structure):
                 ("eager", ctypes.c_int32), ("komi", ctypes.c_float), ("record_visits", ctypes.c_int32),
                 ("prune", ctypes.c_int32), ("speculate", ctypes.c_int32),
                 ("speculate_rows", ctypes.c_int32), ("request_tasks", ctypes.c_int32), ("eager_top", ctypes.c_int32),
-                ("request_steps", ctypes.c_int32 * 3)]
+                ("request_steps", ctypes.c_int32 * 3), ("branch_num", ctypes.c_int32)]
 
 
 class NodeInfo(ctypes.Structure):

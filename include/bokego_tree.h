@@ -71,6 +71,10 @@ typedef struct bk_search_params {
     int32_t request_steps[3]; /* the sizes at which a request gets dearer, ascending, [0] = request_tasks (fp32 engine: 64, 80,
                               128 -- 4 / 3 / 2 CUs per board): a request that is already beyond one step -- an expansion whose
                               priors are not known yet sends all its children -- takes passengers up to the next one     */
+    int32_t branch_num;    /* MCTS kwarg branch_num (mcts.py:62,189-190, Go_MCTS.find_children(k), mcts.py:309-317): > 0 and < 81: a
+                              node's children are the LEGAL moves among the branch_num moves with the highest prior (ties: lower
+                              point first), so a node is expanded once its policy is known -- an expansion whose priors are still
+                              out waits for them (one request) and happens before the next rollout.  0: every legal move         */
 } bk_search_params;
 
 typedef struct bk_game_info {

@@ -294,3 +294,25 @@ def test_choose_below_the_root_leaves_the_root_alone():
     over.play_pass()
     over._terminal = over.is_game_over()
     assert over._terminal and nat.choose(over) is over
+
+
+@pytest.mark.parametrize("k", [5, 12])
+def test_branch_num_on_the_native_tree_is_the_python_trees_search(k):
+    """MCTS kwarg branch_num (mcts.py:62,189-190; find_children(k), mcts.py:309-317): a node's children are the legal moves among
+    the policy's k best -- so an expansion needs the node's priors first.  The native tree (bk_search_params.branch_num) against
+    bokego_amd.mcts.MCTS with the same kwarg: the same children, visit counts and summed values after every move, the same
+    moves; and no node ever has more than k children."""
+    f = FakeNets()
+    # row by row: a BLAS matmul's bits depend on the batch's shape, and the two trees batch their requests differently
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    py = MCTS(Go_MCTS(), _Wrap(pol), _Wrap(val, True), expand_thresh=6, branch_num=k)
+    nat = NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True), expand_thresh=6, branch_num=k)
+    for ply in range(6):
+        py.rollout(200); nat.rollout(200)
+        want = {c.mv: (py.N[c], py.V[c]) for c in py.children[py.root]}
+        assert nat.child_stats() == want and 0 < len(want) <= k, ply
+        a, b = py.choose(), nat.choose()
+        assert a.last_move == b.last_move
+    assert max(len(nat.children[n]) for n in nat.children) <= k
+    assert nat._pool.info(0)["root_N"] == py.N[py.root]
