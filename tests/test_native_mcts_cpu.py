@@ -222,12 +222,13 @@ def test_best_prior_children_only_is_the_same_search_on_one_tree(speculate):
 
 
 def test_unsupported_modes_are_refused_not_ignored():
-    """kwargs of the reference's MCTS that the native tree does not implement (simulation mode, mcts.py:58; branch_num,
-    mcts.py:62,189-190) raise instead of silently running a different search."""
+    """kwargs of the reference's MCTS that the native tree does not implement (simulation mode, mcts.py:58; the degenerate
+    branch_num = 0, which gives every node an empty child set) raise instead of silently running a different search."""
     with pytest.raises(NotImplementedError):
         NativeMCTS(None, evaluator=object(), no_sim=False)
+    f = FakeNets()
     with pytest.raises(NotImplementedError):
-        NativeMCTS(None, evaluator=object(), branch_num=5)
+        NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), branch_num=0)
 
 
 @pytest.mark.parametrize("speculate", [0, 8])
