@@ -618,6 +618,7 @@ struct bk_pool {
     // the same opening -- travel once; row_of[a] = for the a-th active game the batch row of each of its request rows (policy
     // rows first, then value rows), as laid out by collect_dedup
     bool dedup = false;
+    bool mapped = false;          // the batch now out was laid out by collect_dedup (deliver reads row_of)
     std::vector<std::vector<int>> row_of;
     std::vector<bk_pos> uniq_pol, uniq_val;
     uint64_t rows_requested = 0, rows_sent = 0;
@@ -925,6 +926,7 @@ int collect_impl(bk_pool* p, int cap, int* n_policy, Emit emit) {
     p->active.clear();
     p->pol_off.clear();
     p->val_off.clear();
+    p->mapped = false;
     int npol = 0, nval = 0;
     // task_cap: the batch stops growing where the engine's launch would need another round of workgroups (bk_pool_set_task_cap);
     // a game whose request does not fit keeps it and goes first next time
@@ -1083,6 +1085,7 @@ int collect_dedup(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
         for (int& r : rows_a)
             if (r < 0) r = npol + (-r - 1);
     p->rows_sent += (uint64_t)(npol + nval);
+    p->mapped = true;
     p->t_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     *n_policy = npol;
     return npol + nval;
@@ -1175,7 +1178,7 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
         nval += (int)p->games[p->active[a]].req_value.size();
     }
     const int A = (int)p->active.size();
-    const bool mapped = p->dedup && p->row_of.size() == p->active.size();   // the batch was laid out by collect_dedup
+    const bool mapped = p->mapped;                                          // the batch was laid out by collect_dedup
     auto deliver_game = [&](int a) {
         Game& gm = p->games[p->active[a]];
         if (mapped) {
