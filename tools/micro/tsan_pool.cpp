@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
         for (int g = 0; g < G; ++g) seeds[g] = 30260 + 2 * g + p;
         par[p] = bk_pool_create(G, &prm, seeds.data(), threads);
         if (!par[p]) return 2;
+        bk_pool_set_dedup(par[p], 1);     // the de-duplicating collect: liberty refresh in the lanes, hashing on the caller
     }
     {
         std::thread a([&] { while (step(par[0], psteps[0], prows[0])) {} }), b([&] { while (step(par[1], psteps[1], prows[1])) {} });
