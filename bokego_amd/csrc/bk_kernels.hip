@@ -23,9 +23,13 @@
 // mode) is folded into the weights on the host in fp64.
 // Batches of at most 128 (net, board) tasks take the cooperative form further down instead: 2 .. 12 workgroups on as
 // many CUs share one board, each computing a slice of every layer and exchanging slices through L2 (same bits).
+//   * every conv dot product is summed in TWO fp32 chains (the halves of the kernel window), the heads in four: as close to
+//     the float64 evaluation of the network as the reference's own fp32 is (conv_layer below; tools/emu/kernel_emu.c
+//     reproduces the order on the CPU bit for bit).
 // History: round 1 used 32-row tiles (v_mfma_f32_32x32x2_f32), an XOR-swizzled LDS layout and one wave per
-// SIMD; every later form was checked bit-identical to it on the GPU (tools/ab_bits.py), which is why the channel slots of
-// layers 0..5 are kept in the permuted order bk_slot_perm: it reproduces that kernel's summation order.
+// SIMD; rounds 2-3 were checked bit-identical to it on the GPU (tools/ab_bits.py), which is why the channel slots of
+// layers 0..5 are kept in the permuted order bk_slot_perm (it reproduced that kernel's one-chain summation order); round 4
+// changed the order on purpose (two chains) and is checked against the reference and the emulation instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
