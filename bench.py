@@ -926,10 +926,8 @@ def main():
     dist_backend = backend if dist is not None else None
     rank0_cpus = format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None
     others = None
-    if dist is not None:
-        others = [None] * world
-        dist.all_gather_object(others, os.getpid())
-        others = [p for p in others if p != os.getpid()]
+    if dist is not None:      # (the tensor collective the line's other fields use, not all_gather_object: nothing new for RCCL's first N > 1 run)
+        others = [int(p) for p in gather(float(os.getpid())) if int(p) != os.getpid()]
     if rank != 0:
         eng.close()                              # the GPU is let go of before the group is: rank 0's counter passes come next
     if not leave_the_group(dist, rank, world, others):

@@ -181,3 +181,25 @@ def test_analyze_and_tree_views_on_the_native_tree_on_gpu(sds):
     assert torch.equal(nat.root.dist.probs, py.root.dist.probs)
     gen = nat.send("analyze w 10")
     assert next(gen) == "= \n" and next(gen).startswith("info move ")
+
+
+def test_branch_num_and_choose_below_the_root_on_the_engine(sds):
+    """The two kwargs / calls the native tree gained in round 4, on the product path (HIP nets, GPU-encoded planes): branch_num = 8
+    (mcts.py:62,189-190) gives the Python tree's search visit for visit over four 600-rollout moves, and choose(node) for a child
+    of the root (mcts.py:110-131) returns the same grandchild on both trees without moving either root."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts import MCTS, Go_MCTS
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    pi, val = nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1])
+    py = MCTS(Go_MCTS(), pi, val, branch_num=8)
+    nat = NativeMCTS(Position(), pi, val, branch_num=8)
+    for ply in range(4):
+        py.rollout(600); nat.rollout(600)
+        want = {c.mv: (py.N[c], py.V[c]) for c in py.children[py.root]}
+        assert nat.child_stats() == want and 0 < len(want) <= 8, ply
+        root_key = nat.root.key()
+        for c in py.children[py.root]:
+            if c in py.children and py.children[c]:
+                assert nat.choose(nat.root.make_move(c.last_move)).key() == py.choose(c).key()
+        assert nat.root.key() == root_key == py.root.key()
+        assert py.choose().last_move == nat.choose().last_move
