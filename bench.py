@@ -444,8 +444,9 @@ def leave_the_group(dist, rank, world, pids=None):
             for p in pids:
                 try:
                     os.kill(p, 0)
-                    alive.append(p)
-                except OSError:
+                    if open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[0] != "Z":   # (a zombie waiting for its launcher is gone)
+                        alive.append(p)
+                except (OSError, IndexError):
                     pass
             pids = alive
             time.sleep(0.1)
@@ -483,8 +484,8 @@ def launch_selftest(args):
     for p in pids[1:]:
         try:
             os.kill(p, 0)
-            gone.append(False)
-        except OSError:
+            gone.append(open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[0] == "Z")
+        except (OSError, IndexError):
             gone.append(True)
     print(json.dumps({"n_gpus": world, "collective_ranks_seen": seen, "collective_backend": "gloo",
                       "sum_of_ranks_plus_1": float(t.item()), "rank_cpus": cpus, "steps": args.steps,
