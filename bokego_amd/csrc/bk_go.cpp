@@ -432,6 +432,29 @@ int bk_pos_eye_like(const bk_pos* p, int sq, int color) {
     return 1;
 }
 
+// go.possible_eye (go.py:470-485) as the reference computes it, table bug included: DIAGONALS (go.py:372-373) lists
+// (x+1,y+1), (x+1,y-1), (x-1,y-1) and (x-1,y-1) AGAIN -- (x-1,y+1) is never looked at and (x-1,y-1) counts twice.
+// Returns the colour of the one-point eye at sq (BK_BLACK / BK_WHITE) or 0.
+int bk_pos_possible_eye(const bk_pos* p, int sq) {
+    if (sq < 0 || sq >= NN || p->board[sq] == BK_BLACK || p->board[sq] == BK_WHITE) return 0;
+    const int8_t color = p->board[T.nbr[sq][0]];           // possible_ko (go.py:461-468): one colour all around, no empties
+    if (color != BK_BLACK && color != BK_WHITE) return 0;
+    for (int k = 1; k < T.nn[sq]; ++k)
+        if (p->board[T.nbr[sq][k]] != color) return 0;
+    const int x = sq / N, y = sq % N;
+    static const int dx[4] = {1, 1, -1, -1}, dy[4] = {1, -1, -1, -1};
+    int on_board = 0, faults = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int a = x + dx[k], b = y + dy[k];
+        if (a < 0 || a >= N || b < 0 || b >= N) continue;
+        ++on_board;
+        const int8_t c = p->board[a * N + b];
+        if (c == BK_BLACK || c == BK_WHITE) faults += c != color;
+    }
+    if (on_board < 4) ++faults;
+    return faults > 1 ? 0 : color;
+}
+
 void bk_pos_features_u8(bk_pos* p, uint8_t out[2187], int fresh) { features_impl(p, out, fresh); }
 void bk_pos_features_f32(bk_pos* p, float out[2187], int fresh) { features_impl(p, out, fresh); }
 

@@ -43,6 +43,7 @@ GO_SYMBOLS = {
     "bk_pos_score": (ctypes.c_float, [_PP, ctypes.c_float]),
     "bk_pos_area_score": (ctypes.c_float, [_PP, ctypes.c_float]),
     "bk_pos_eye_like": (ctypes.c_int, [_PP, ctypes.c_int, ctypes.c_int]),
+    "bk_pos_possible_eye": (ctypes.c_int, [_PP, ctypes.c_int]),
     "bk_pos_features_u8": (None, [_PP, ctypes.c_void_p, ctypes.c_int]),
     "bk_pos_features_f32": (None, [_PP, ctypes.c_void_p, ctypes.c_int]),
     "bk_features_batch_u8": (None, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),

@@ -94,6 +94,7 @@ class Go_MCTS(go.Game):
         c.play_move(index)
         c.mv = int(c._pos.last_move)
         c._terminal = c.is_game_over()
+        c.tree = self.tree            # the reference deep-copies the node, tree link included (mcts.py:343)
         return c
 
     def find_children(self, k=None):
@@ -123,7 +124,7 @@ class Go_MCTS(go.Game):
         move = d.sample().item()
         color = 1 if self.turn % 2 == 0 else 2
         tries = 0
-        while not self.is_legal(move) or go.golib().bk_pos_eye_like(ctypes.byref(self._pos), move, color):
+        while not self.is_legal(move) or go.golib().bk_pos_possible_eye(ctypes.byref(self._pos), move) == color:
             if tries >= go.N ** 2:
                 return go.PASS
             d.probs[move] = 0

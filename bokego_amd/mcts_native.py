@@ -327,7 +327,7 @@ class NativeMCTS:
         d.probs = pr
         color = 1 if node.turn % 2 == 0 else 2
         move, tries = d.sample().item(), 0
-        while not node.is_legal(move) or go.golib().bk_pos_eye_like(ctypes.byref(node._pos), move, color):
+        while not node.is_legal(move) or go.golib().bk_pos_possible_eye(ctypes.byref(node._pos), move) == color:
             d.probs[move] = 0                            # as the reference: a rejected move is not drawn again
             if tries >= go.N ** 2 or not float(d.probs.sum()) > 0:
                 move = go.PASS

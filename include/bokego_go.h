@@ -73,6 +73,10 @@ float bk_pos_score(const bk_pos *p, float komi);
 float bk_pos_area_score(const bk_pos *p, float komi);
 /* single-point eye test used by the build's playout generator: all on-board neighbours are `color` */
 int bk_pos_eye_like(const bk_pos *p, int sq, int color);
+/* go.possible_eye go.py:470-485 with the reference's DIAGONALS table (go.py:372-373: (x-1,y-1) twice, (x-1,y+1) never): the
+ * colour (BK_BLACK / BK_WHITE) of the one-point eye at sq, or 0.  Go_MCTS.get_move (mcts.py:354) rejects a sampled move when
+ * this is the mover's own colour. */
+int bk_pos_possible_eye(const bk_pos *p, int sq);
 
 /* nnet.features() nnet.py:182-262: 27 planes x 81, values 0..7 */
 void bk_pos_features_u8(bk_pos *p, uint8_t out[2187], int fresh);

@@ -161,3 +161,30 @@ def test_children_without_a_flood_fill_per_move_equal_the_definition():
                 libs = (ctypes.c_uint8 * 81)()
                 lib.bk_pos_liberties(ctypes.byref(pos), libs)
     assert checked > 20000 and caps > 300
+
+
+def test_possible_eye_matches_the_reference_table_bug_included():
+    """go.possible_eye (go.py:470-485) on 1,392 boards x 81 points recorded from the reference (tools/gen_eye_golden.py): the
+    one-point-eye test Go_MCTS.get_move uses (mcts.py:354), with the reference's DIAGONALS table (go.py:372-373), which
+    looks at (x-1,y-1) twice and never at (x-1,y+1)."""
+    import ctypes
+    z = np.load(os.path.join(GOLDEN, "possible_eye.npz"))
+    lib = go.golib()
+    n_eyes = 0
+    for b, want in zip(z["boards"], z["eyes"]):
+        g = go.Game(board="".join(".XO"[c] for c in b))
+        got = np.array([lib.bk_pos_possible_eye(ctypes.byref(g._pos), s) for s in range(81)], np.int8)
+        assert (got == want).all(), ("".join(".XO"[c] for c in b), np.nonzero(got != want)[0])
+        n_eyes += int((want > 0).sum())
+    assert n_eyes > 500
+    # the blind corner: black stones around E5 and white stones on the two diagonals the table does see twice / never
+    board = ["."] * 81
+    for s in (3 * 9 + 4, 5 * 9 + 4, 4 * 9 + 3, 4 * 9 + 5):
+        board[s] = "X"
+    board[3 * 9 + 5] = "O"          # (x-1, y+1): never looked at
+    board[5 * 9 + 5] = "O"          # (x+1, y+1): one fault -> still an eye
+    g = go.Game(board="".join(board))
+    assert lib.bk_pos_possible_eye(ctypes.byref(g._pos), 40) == 1
+    board[3 * 9 + 3] = "O"          # (x-1, y-1): counted twice -> three faults
+    g = go.Game(board="".join(board))
+    assert lib.bk_pos_possible_eye(ctypes.byref(g._pos), 40) == 0

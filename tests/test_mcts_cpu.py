@@ -169,3 +169,33 @@ def test_pickle_and_deepcopy_keep_the_search_state(nets):
     assert {k.mv: (b.N[k], b.V[k]) for k in b.children[b.root]} == after
     assert {k.mv: (c.N[k], c.V[k]) for k in c.children[c.root]} == after
     assert a.choose().last_move == b.choose().last_move == c.choose().last_move
+
+
+def test_simulation_mode_playouts_follow_the_reference_up_to_where_it_raises(nets):
+    """MCTS(no_sim=False) (boke.py --simulate): the first playout from the empty board draws the reference's moves, seed for
+    seed (tests/golden/simulate_playouts.json, recorded from the reference: Go_MCTS.get_move, mcts.py:348-360, with
+    go.possible_eye and torch's sampler) -- up to the draw at which the reference raises "invalid multinomial distribution"
+    because every acceptable move is used up (its pass-as-a-last-resort branch is unreachable); there this build passes,
+    which ends the playout.  No search of the reference gets past its first rollouts in this mode (also in the fixture)."""
+    gold = json.load(open(os.path.join(GOLDEN, "simulate_playouts.json")))
+    assert all(s["error"] and s["rollouts_done"] <= 1 for s in gold["searches_of_40_rollouts"])
+    for rec in gold["playouts"]:
+        torch.manual_seed(rec["seed"])
+        tree = MCTS(Go_MCTS(), _TorchWrap(nets[0]), None, no_sim=False)
+        node, moves = tree.root, []
+        while not node._terminal:
+            node = node.find_random_child()
+            moves.append(node.last_move)
+        assert rec["raised"] and rec["acceptable_moves_left"] == 0
+        assert moves[:-1] == rec["moves"], rec["seed"]
+        assert moves[-1] == go.PASS
+        assert float(node.score()) == rec["score"]
+    # and a whole search runs through: N and Q stay consistent (every rollout adds +-1 to Q along its path)
+    torch.manual_seed(1)
+    tree = MCTS(Go_MCTS(), _TorchWrap(nets[0]), None, no_sim=False, expand_thresh=3)
+    tree.rollout(12)
+    root = tree.root
+    assert tree.N[root] == 12 and abs(tree.Q[root]) <= 12 and tree.Q[root] % 2 == 0 and tree.V[root] == 0
+    kids = tree.children[root]
+    assert sum(tree.N[c] for c in kids) == 12          # the root is always expanded (mcts.py:157): every rollout goes through a child
+    assert sum(tree.Q[c] for c in kids) == -tree.Q[root]
