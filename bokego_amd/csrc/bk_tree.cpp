@@ -30,13 +30,14 @@
 
 namespace {
 
-// 48 bytes: the search (select / backprop) walks these and nothing else; the 192-byte position of node i is poses[i]
+// 56 bytes: the search (select / backprop) walks these and nothing else; the 192-byte position of node i is poses[i]
 // (read when a node is interned, expanded or sent for evaluation).  A node's children are interned together, so their
 // statistics are mostly neighbours in memory.  Measured on a synthetic 72-child select (tools/micro/select_bench.cpp):
 // 232-byte nodes with two divisions per child 350 ns, these nodes 240 ns, + the cached average 185 ns.
 struct TNode {
     double V = 0.0;
     double avg = 0.0;  // N == 0 ? 0 : V / N, refreshed where V and N change (backprop): select divides once per child
+                       // (simulation mode: ((1 - w) Q + w V) / N, mcts.py:227-230)
     int N = 0;
     float value = 0.f;
     uint8_t has_value = 0, has_prior = 0, expanded = 0, terminal = 0;
@@ -44,9 +45,10 @@ struct TNode {
     int kids_off = 0, n_kids = 0;
     int prior_off = -1;
     int mv = BK_NO_MOVE;
+    double Q = 0.0;    // summed playout rewards (MCTS.Q[node]); stays 0 unless prm.simulate
 };
 
-enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_WAIT_LEAF, S_CHOOSE, S_DONE, S_IDLE };
+enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_PLAYOUT, S_WAIT_LEAF, S_CHOOSE, S_DONE, S_IDLE };
 
 struct Rng {  // xoshiro256** seeded by splitmix64: per-game stream, independent of how games are sharded
     uint64_t s[4];
@@ -271,7 +273,7 @@ struct Game {
     // node's prior order it tends to go on (all visited children looking bad), and one request then serves the next visits.
     void request_leaf() {
         const int leaf = path.back();
-        if (nodes[leaf].has_value || queued_value(leaf)) return;
+        if (!prm.use_value || nodes[leaf].has_value || queued_value(leaf)) return;
         req_value.push_back(leaf);
         if (prm.eager_top > 0 && path.size() >= 2) {
             const int parent = path[path.size() - 2];
@@ -371,7 +373,103 @@ struct Game {
         if (spec_queue.empty()) spec_kids.clear();
     }
 
+    // ---- simulation mode (MCTS(no_sim=False), boke.py --simulate; mcts.py:147-148,195-206) ---------------------------------
+    // A rollout's score is the result of a playout from its leaf: moves sampled from the policy (Go_MCTS.get_move,
+    // mcts.py:348-360: a sampled move that is illegal or fills the mover's own one-point eye is zeroed in the node's
+    // distribution and another one drawn), to the end of the game (a pass or turn > max_turns, mcts.py:362-364), scored by
+    // Game.score (mcts.py:338; the gnugo scorer needs a binary).  Where no acceptable move is left the playout PASSES -- what
+    // the reference's docstring says; its own code raises there (the branch needs 82 non-zero probabilities) and no search
+    // of it gets through its first rollouts (tests/golden/simulate_playouts.json).
+    // A playout position that is a node of the tree (the leaf itself, a transposition) uses -- and changes, as the
+    // reference's cached distribution is changed -- that node's priors; any other one lives only for the playout: nodes with
+    // an id >= po_mark keep their priors in po_priors and are dropped when the playout ends (the reference keeps every
+    // position it ever evaluated, without bound).  Draws come from the game's own generator (inverse CDF over the
+    // unnormalised probabilities), not from torch's.
+    int po = -1, po_mark = -1, po_reward = 0;
+    std::vector<double> po_priors;
+    bool transient(int id) const { return po_mark >= 0 && id >= po_mark; }
+    double* prior_ptr(int id) { return transient(id) ? &po_priors[nodes[id].prior_off] : &priors[nodes[id].prior_off]; }
+
+    int sample_move(int id) {
+        double* pr = prior_ptr(id);
+        const bk_pos& ps = poses[id];
+        const int color = (ps.turn & 1) ? BK_WHITE : BK_BLACK;
+        auto draw = [&]() {
+            double tot = 0;
+            for (int i = 0; i < 81; ++i) tot += pr[i];
+            if (!(tot > 0)) return -1;
+            const double u = rng.uniform() * tot;
+            double c = 0;
+            int last = -1;
+            for (int i = 0; i < 81; ++i) {
+                if (!(pr[i] > 0)) continue;
+                c += pr[i];
+                last = i;
+                if (u < c) return i;
+            }
+            return last;
+        };
+        int mv = draw();
+        for (int tries = 0; mv >= 0 && (!bk_pos_is_legal(&ps, mv) || bk_pos_possible_eye(&ps, mv) == color); ++tries) {
+            if (tries >= 81) return BK_PASS;
+            pr[mv] = 0;
+            mv = draw();
+        }
+        return mv < 0 ? BK_PASS : mv;
+    }
+
+    void drop_transient() {   // the playout's own nodes, newest first: with linear probing the newest entry is always safe to remove
+        if (po_mark < 0) return;
+        const size_t mask = slots.size() - 1;
+        for (int id = (int)nodes.size() - 1; id >= po_mark; --id) {
+            size_t i = mix(key_hash(poses[id])) & mask;
+            while (slots[i] != id) i = (i + 1) & mask;
+            slots[i] = -1;
+        }
+        nodes.resize((size_t)po_mark);
+        poses.resize((size_t)po_mark);
+        po_priors.clear();
+        po_mark = -1;
+    }
+
+    // true: the playout is over (po_reward is the rollout's score, from the point of view of the side to move at the leaf,
+    // mcts.py:199-204); false: a position's policy has been asked for
+    bool playout() {
+        if (po < 0) {
+            po = path.back();
+            po_mark = (int)nodes.size();
+        }
+        while (!nodes[po].terminal) {
+            if (!nodes[po].has_prior) {
+                if (std::find(req_policy.begin(), req_policy.end(), po) == req_policy.end()) req_policy.push_back(po);
+                return false;
+            }
+            const int mv = sample_move(po);
+            bk_pos c = poses[po];
+            bk_pos_play(&c, mv);
+            po = intern(c);
+        }
+        int r = bk_pos_score(&poses[po], prm.komi) > 0 ? 1 : -1;
+        if (poses[path.back()].turn & 1) r = -r;
+        po_reward = r;
+        po = -1;
+        drop_transient();
+        return true;
+    }
+
     void backprop() {  // mcts.py:208-217
+        if (prm.simulate || !prm.use_value) {
+            double v = (double)nodes[path.back()].value, r = (double)po_reward;
+            const double w = prm.value_weight;
+            for (int i = (int)path.size() - 1; i >= 0; --i) {
+                TNode& n = nodes[path[i]];
+                n.N += 1;
+                if (prm.simulate) { n.Q += r; r = -r; }
+                if (prm.use_value) { n.V += v; v = -v; }
+                n.avg = ((1 - w) * n.Q + w * n.V) / (double)n.N;
+            }
+            return;
+        }
         if (prm.speculate > 0) {
             const TNode& leaf = nodes[path.back()];
             if (!leaf.expanded && !leaf.terminal && !leaf.speculated && leaf.N + 1 == prm.speculate) spec_queue.push_back(path.back());
@@ -525,7 +623,7 @@ struct Game {
                     state = S_SEARCH;
                     break;
                 case S_SEARCH: {
-                    bool waiting = false;
+                    bool waiting = false, playing = false;
                     while (remaining > 0) {
                         path.clear();
                         int id = root;
@@ -540,9 +638,14 @@ struct Game {
                         }
                         if (analyze && path.size() > 2) variations[path[1]].assign(path.begin() + 1, path.end());
                         request_leaf();
+                        if (prm.simulate) { playing = true; break; }
                         if (has_request()) { waiting = true; break; }
                         backprop();
                         --remaining;
+                    }
+                    if (playing) {
+                        state = S_PLAYOUT;
+                        break;
                     }
                     if (waiting) {
                         add_speculation();
@@ -552,6 +655,29 @@ struct Game {
                     state = manual ? S_IDLE : S_CHOOSE;
                     break;
                 }
+                case S_PLAYOUT:
+                    if (pending_expand >= 0) {                       // branch_num: the leaf is expanded before its playout starts
+                        if (!nodes[pending_expand].has_prior) {      // (the playout's own nodes must be the newest ones)
+                            add_speculation();
+                            return true;
+                        }
+                        const int id = pending_expand;
+                        pending_expand = -1;
+                        expand(id);
+                    }
+                    if (!playout()) {
+                        add_speculation();
+                        return true;
+                    }
+                    if (has_request()) {                             // the leaf's value (and what travels with it) is still out
+                        add_speculation();
+                        state = S_WAIT_LEAF;
+                        return true;
+                    }
+                    backprop();
+                    --remaining;
+                    state = S_SEARCH;
+                    break;
                 case S_WAIT_LEAF:
                     if (pending_expand >= 0) {                       // branch_num: the leaf's priors are in: expand it before
                         const int id = pending_expand;               // the next rollout (what it asks for rides with a later request)
@@ -591,8 +717,9 @@ struct Game {
     void deliver_policy(int id, const float* probs) {
         TNode& n = nodes[id];
         if (!n.has_prior) {
-            n.prior_off = (int)priors.size();
-            for (int i = 0; i < 81; ++i) priors.push_back((double)probs[i]);
+            std::vector<double>& dst = transient(id) ? po_priors : priors;
+            n.prior_off = (int)dst.size();
+            for (int i = 0; i < 81; ++i) dst.push_back((double)probs[i]);
             n.has_prior = 1;
             ++n_policy_evals;
         }
@@ -643,13 +770,19 @@ void bk_search_params_default(bk_search_params* p) {
     p->request_tasks = 0;
     p->request_steps[0] = p->request_steps[1] = p->request_steps[2] = 0;
     p->branch_num = 0;
+    p->simulate = 0;
+    p->use_value = 1;
+    p->value_weight = 1.0;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {
     if (n_games <= 0 || !prm || !seeds) return nullptr;
     bk_pool* p = new bk_pool();
     p->games.reserve(n_games);
-    for (int i = 0; i < n_games; ++i) p->games.emplace_back(*prm, seeds[i]);
+    bk_search_params q = *prm;
+    if (!q.use_value) q.eager = q.eager_top = 0;                 // no value net (mcts.py:68-69): nothing asks for a value
+    if (!q.use_value || q.simulate) q.speculate = 0;             // (a playout's nodes must stay the newest ones of the tree)
+    for (int i = 0; i < n_games; ++i) p->games.emplace_back(q, seeds[i]);
     p->threads = threads > 0 ? threads : 1;
     return p;
 }
@@ -1361,6 +1494,14 @@ int bk_pool_node(const bk_pool* p, int g, int id, bk_node_info* out, bk_pos* pos
                                 (n.has_value ? BK_NODE_HAS_VALUE : 0) | (n.has_prior ? BK_NODE_HAS_PRIOR : 0));
     }
     if (pos) *pos = gm.poses[id];
+    return 0;
+}
+
+int bk_pool_node_q(const bk_pool* p, int g, int id, double* q) {
+    if (g < 0 || g >= (int)p->games.size() || !q) return -1;
+    const Game& gm = p->games[g];
+    if (id < 0 || id >= (int)gm.nodes.size()) return -1;
+    *q = gm.nodes[id].Q;
     return 0;
 }
 

@@ -53,6 +53,9 @@ GO_SYMBOLS = {
 _golib = None
 
 
+GO_ABI_VERSION = 4     # include/bokego_go.h + bokego_tree.h (bk_go_abi_version)
+
+
 def golib():
     global _golib
     if _golib is None:
@@ -63,6 +66,9 @@ def golib():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         assert ctypes.sizeof(Pos) == 192
+        if lib.bk_go_abi_version() != GO_ABI_VERSION:
+            raise RuntimeError(f"{GO_LIB_PATH} is ABI {lib.bk_go_abi_version()}, this package needs {GO_ABI_VERSION}: "
+                               "rebuild it with `make -C bokego_amd/csrc`")
         _golib = lib
     return _golib
 

@@ -407,7 +407,7 @@ def build_parser():
     ap.add_argument("-g", "--gpu", type=int, nargs="?", const=0, default=0, metavar="INDEX",
                     help="GPU index (default 0; the networks always run on the GPU -- a bare -g is accepted as in the reference)")
     ap.add_argument("--simulate", action="store_true",
-                    help="enable simulations to end of game (slow; the reference's flag: searches with the Python tree)")
+                    help="enable simulations to end of game (the reference's flag, boke.py:24: no_sim=False -- playouts sampled from the policy)")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default=None,
                     help="conv arithmetic: f32 (default, the reference's width) or the opt-in split-fp16 fast path")
     ap.add_argument("--ponder", action="store_true")
@@ -421,8 +421,7 @@ def main(argv=None):
     from . import nnet
     pi = nnet.HipPolicyNet(load_state_dict(args.p), device_id=args.gpu, precision=args.precision)
     val = nnet.HipValueNet(load_state_dict(args.v), device_id=args.gpu, precision=args.precision)
-    python_tree = args.python_tree or args.simulate      # the native tree implements the no-simulation mode only
-    cls, root = (GTP, Go_MCTS()) if python_tree else (NativeGTP, Position())
+    cls, root = (GTP, Go_MCTS()) if args.python_tree else (NativeGTP, Position())
     gtp = cls(root, pi, val, no_sim=not args.simulate, time_lim=None if args.r else args.t, n_rollouts=args.r, pondering=args.ponder)
     gtp.start()
 

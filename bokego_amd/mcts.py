@@ -121,6 +121,8 @@ class Go_MCTS(go.Game):
     def get_move(self):
         """Sample a legal, non-eye-filling move from the policy; pass as a last resort (mcts.py:348-360)."""
         d = self.dist
+        if not float(d.probs.sum()) > 0:           # a node whose moves were all used up by an earlier playout
+            return go.PASS
         move = d.sample().item()
         color = 1 if self.turn % 2 == 0 else 2
         tries = 0

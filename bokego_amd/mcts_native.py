@@ -78,13 +78,20 @@ class _TreeView(Mapping):
     def __init__(self, tree, field):
         self._tree, self._field = tree, field
 
+    def _read(self, i):
+        if self._field == "Q":      # summed playout rewards: 0 everywhere unless the tree simulates (no_sim=False)
+            q = ctypes.c_double()
+            self._tree._lib.bk_pool_node_q(self._tree._pool._h, 0, int(i), ctypes.byref(q))
+            return q.value
+        return getattr(self._tree._node_at(i), self._field)
+
     def __getitem__(self, node):
-        info = self._tree._node_info(node)
-        return 0 if info is None or self._field is None else getattr(info, self._field)
+        i = self._tree._find(node)
+        return 0 if i < 0 else self._read(i)
 
     def get(self, node, default=0):
-        info = self._tree._node_info(node)
-        return default if info is None else (0 if self._field is None else getattr(info, self._field))
+        i = self._tree._find(node)
+        return default if i < 0 else self._read(i)
 
     def __contains__(self, node):
         return self._tree._find(node) >= 0
@@ -128,10 +135,11 @@ class NativeMCTS:
         if policy_net is None and kwargs.get("evaluator") is None:
             raise TypeError("Missing required keywork argument: 'policy_net'")
         self.no_sim = kwargs.get("no_sim", True)
-        if not self.no_sim:
-            raise NotImplementedError("NativeMCTS implements the no-simulation mode only")
-        if value_net is None and kwargs.get("evaluator") is None:
+        if value_net is None and self.no_sim and kwargs.get("evaluator") is None:
             raise TypeError("Keyword argument 'value_net' is required for no simulation mode")
+        # no_sim=False (boke.py --simulate; mcts.py:58,147-148): rollouts end in a policy playout, bk_search_params.simulate.
+        # `has_value`: with an `evaluator` instead of nets, whether it computes values (default True).
+        has_value = value_net is not None or (kwargs.get("evaluator") is not None and kwargs.get("has_value", True))
         # mcts.py:62,189-190: children = the legal moves among the policy's top k (bk_search_params.branch_num: an expansion then
         # waits for the node's priors).  None / 0 / >= 81: every legal move.
         self.branch_num = kwargs.get("branch_num")
@@ -139,15 +147,19 @@ class NativeMCTS:
         self.expand_thresh = kwargs.get("expand_thresh", 100)
         self.exploration_weight = kwargs.get("exploration_weight", 4.0)
         self.noise_weight = kwargs.get("noise_weight", 0)
-        self.value_net_weight = 1.0
+        # mcts.py:65-72
+        self.value_net_weight = 1.0 if self.no_sim else (0.0 if not has_value else kwargs.get("value_net_weight", 0.5))
         ev = kwargs.get("evaluator")
         if ev is None:
             if isinstance(policy_net, nnet.HipPolicyNet) and isinstance(value_net, nnet.HipValueNet):
                 ev = selfplay.EngineEvaluator(nnet.fuse(policy_net, value_net, kwargs.get("max_batch")))
+            elif isinstance(policy_net, nnet.HipPolicyNet) and value_net is None:
+                ev = selfplay.EngineEvaluator(policy_net.engine(), value=False)
             else:  # any callables: policy(x)->logits, value(x)->[B,1]  (CPU tests use the oracle nets)
                 import torch
                 ev = selfplay.CallableEvaluator(lambda x: policy_net(torch.from_numpy(x)).numpy(),
-                                                lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1))
+                                                None if value_net is None else
+                                                (lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1)))
         self.evaluator = ev
         # Evaluation ahead of expansion (bokego_tree.h, `speculate`): same search, fewer round trips, more rows per request.
         # It pays as long as the bigger request costs about the same: the f16x2 kernel runs <= 256 rows as one round of
@@ -165,12 +177,14 @@ class NativeMCTS:
                                      speculate=spec[0], speculate_rows=spec[1], request_tasks=spec[2],
                                      request_steps=kwargs.get("request_steps", (spec[2], 80, 128) if spec[2] == 64 else (spec[2],)))
         prm.eager_top = kwargs.get("eager_top", EAGER_TOP)
+        prm.simulate, prm.use_value, prm.value_weight = int(not self.no_sim), int(has_value), float(self.value_net_weight)
         if self.branch_num is not None and 0 <= self.branch_num < go.N ** 2:
             if self.branch_num == 0:
                 raise NotImplementedError("branch_num = 0 (no children at all) is not a search; use bokego_amd.mcts.MCTS to reproduce it")
             prm.branch_num = int(self.branch_num)
         self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=kwargs.get("cap", 1024), threads=1)
-        self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, None)   # Q: simulations are off
+        self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, "Q")
+        self._has_value = has_value
         self.children = _ChildrenView(self)
         self._lib = self._pool._lib
         self._lib.bk_pool_set_manual(self._pool._h, 1)
@@ -239,6 +253,8 @@ class NativeMCTS:
         return d          # dist.probs the same way, mcts.py:357,369,381)
 
     def _value(self, node):
+        if not self._has_value:      # Go_MCTS.value without a value net, mcts.py:395-396
+            return None
         info = self._node_info(node)
         return None if info is None or not info.flags & 4 else float(info.value)
 
@@ -360,16 +376,17 @@ class NativeMCTS:
         self._pump()
 
     def winrate(self, node=None):
-        """(V/N + 1)/2 of the root, or of any node of the tree (mcts.py:159-170); 0 for an unvisited one."""
-        if node is None:
-            gi = self._pool.info(0)
-            n, v = gi["root_N"], gi["root_V"]
-        else:
-            info = self._node_info(node)
-            if info is None:
-                return 0
-            n, v = info.N, info.V
-        return (v / n + 1) / 2 if n > 0 else 0
+        """(((1 - w) Q + w V) / N + 1) / 2 of the root, or of any node of the tree (mcts.py:159-170; w = value_net_weight, 1
+        without simulations); 0 for an unvisited one."""
+        i = self._lib.bk_pool_root_id(self._pool._h, 0) if node is None else self._find(node)
+        if i < 0:
+            return 0
+        info = self._node_at(i)
+        if info.N <= 0:
+            return 0
+        w = self.value_net_weight
+        q = self.Q._read(i) if not self.no_sim else 0.0
+        return (((1 - w) * q + w * info.V) / info.N + 1) / 2
 
     def child_stats(self):
         """{move: (N, V)} of the root's children."""

@@ -31,7 +31,8 @@ class SearchParams(ctypes.Structure):
                 ("eager", ctypes.c_int32), ("komi", ctypes.c_float), ("record_visits", ctypes.c_int32),
                 ("prune", ctypes.c_int32), ("speculate", ctypes.c_int32),
                 ("speculate_rows", ctypes.c_int32), ("request_tasks", ctypes.c_int32), ("eager_top", ctypes.c_int32),
-                ("request_steps", ctypes.c_int32 * 3), ("branch_num", ctypes.c_int32)]
+                ("request_steps", ctypes.c_int32 * 3), ("branch_num", ctypes.c_int32),
+                ("simulate", ctypes.c_int32), ("use_value", ctypes.c_int32), ("value_weight", ctypes.c_double)]
 
 
 class NodeInfo(ctypes.Structure):
@@ -78,6 +79,7 @@ TREE_SYMBOLS = {
     "bk_pool_node": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NodeInfo), _VP]),
     "bk_pool_node_children": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int]),
     "bk_pool_node_prior": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP]),
+    "bk_pool_node_q": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP]),
     "bk_pool_principal_variation": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int]),
     "bk_pool_set_analyze": (None, [_VP, ctypes.c_int]),
     "bk_pool_variation": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int]),
@@ -225,23 +227,28 @@ class EngineEvaluator:
     gpu_encode=True (default): drivers hand over 192-byte position records (GamePool.collect_positions) and
     the engine computes the 27 planes on the GPU; False: host-encoded uint8 planes (GamePool.collect)."""
 
-    def __init__(self, engine, gpu_encode=True):
+    def __init__(self, engine, gpu_encode=True, value=True):
+        """value=False: an engine without a ValueNet (a tree in simulation mode with policy_net only, mcts.py:68-69): only the
+        policy is computed; the values handed back are zeros nobody reads."""
         self.engine = engine
         self.wants_positions = bool(gpu_encode)
+        self.value = bool(value)
         self.positions = self.batches = 0
 
     def submit(self, feats, n_policy):
         self.positions += len(feats)
         self.batches += 1
+        if not self.value and n_policy != len(feats):
+            raise ValueError("value rows in a request for an engine without a ValueNet")
         if feats.ndim == 2:   # [B,192] position records
-            return self.engine.submit_positions(feats, logits=False, probs=n_policy > 0, value=True, n_policy=n_policy), n_policy
-        return self.engine.submit(feats, logits=False, probs=n_policy > 0, value=True, n_policy=n_policy), n_policy
+            return self.engine.submit_positions(feats, logits=False, probs=n_policy > 0, value=self.value, n_policy=n_policy), (n_policy, len(feats))
+        return self.engine.submit(feats, logits=False, probs=n_policy > 0, value=self.value, n_policy=n_policy), (n_policy, len(feats))
 
     def finish(self, handle):
-        t, npol = handle
+        t, (npol, rows) = handle
         out = self.engine.wait(t)
         probs = normalise_like_categorical(out["probs"]) if npol else np.zeros((0, 81), np.float32)
-        return probs, out["value"]
+        return probs, out["value"] if self.value else np.zeros(rows, np.float32)
 
     def __call__(self, feats, n_policy):
         return self.finish(self.submit(feats, n_policy))
@@ -268,6 +275,8 @@ class CallableEvaluator:
             probs = normalise_like_categorical(torch.softmax(lg, dim=1).numpy())
         else:
             probs = np.zeros((0, 81), np.float32)
+        if self.value_fn is None:          # no value net (simulation mode, mcts.py:68-69): zeros nobody reads
+            return probs, np.zeros(len(x), np.float32)
         return probs, np.asarray(self.value_fn(x), dtype=np.float32).reshape(-1)
 
     def __call__(self, feats, n_policy):

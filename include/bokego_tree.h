@@ -75,6 +75,18 @@ typedef struct bk_search_params {
                               node's children are the LEGAL moves among the branch_num moves with the highest prior (ties: lower
                               point first), so a node is expanded once its policy is known -- an expansion whose priors are still
                               out waits for them (one request) and happens before the next rollout.  0: every legal move         */
+    int32_t simulate;      /* MCTS kwarg no_sim = False (boke.py --simulate; mcts.py:58,147-148,195-206): every rollout ends in a
+                              playout from its leaf -- moves sampled from the policy (Go_MCTS.get_move, mcts.py:348-360, with
+                              go.possible_eye), to a pass or turn > max_turns, scored by Game.score -- whose result (+1 / -1 for
+                              the side to move at the leaf) is summed into Q along the path (mcts.py:208-214).  Draws come from
+                              the game's own generator.  Where no acceptable move is left the playout passes (the reference
+                              raises there; see tests/golden/simulate_playouts.json).  Playout positions outside the tree are
+                              evaluated (policy) and forgotten.  Turns evaluation ahead (speculate) off.  0: off            */
+    int32_t use_value;     /* 0: there is no value net (MCTS(value_net=None), mcts.py:68-69): no value is ever asked for, V stays
+                              0; rows that carry one anyway are ignored.  Needs simulate.  1: default                       */
+    double value_weight;   /* MCTS kwarg value_net_weight (mcts.py:65-72): a child's average reward in the selection is
+                              ((1 - w) Q + w V) / N.  1.0 without simulation (the reference forces it), else default 0.5, 0
+                              without a value net                                                                            */
 } bk_search_params;
 
 typedef struct bk_game_info {
@@ -179,6 +191,7 @@ typedef struct bk_node_info {
 int bk_pool_find(const bk_pool *p, int g, const bk_pos *pos);
 int bk_pool_root_id(const bk_pool *p, int g);
 int bk_pool_node(const bk_pool *p, int g, int id, bk_node_info *out, bk_pos *pos);
+int bk_pool_node_q(const bk_pool *p, int g, int id, double *q);    /* MCTS.Q[node]: summed playout rewards (simulate) */
 int bk_pool_node_children(const bk_pool *p, int g, int id, int32_t *ids, int cap);
 int bk_pool_node_prior(const bk_pool *p, int g, int id, double *prior);
 int bk_pool_principal_variation(const bk_pool *p, int g, int16_t *moves, int cap);

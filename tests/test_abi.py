@@ -132,8 +132,8 @@ def test_host_library_exports_go_and_tree_headers():
         assert fns and set(fns) == set(table), (hdr, set(fns) ^ set(table))
         for f in fns:
             assert hasattr(lib, f)
-    assert lib.bk_go_abi_version() == 3
-    assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 80 and C.sizeof(selfplay.NodeInfo) == 24 and C.sizeof(selfplay.GameInfo) == 56
+    assert lib.bk_go_abi_version() == 4
+    assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 96 and C.sizeof(selfplay.NodeInfo) == 24 and C.sizeof(selfplay.GameInfo) == 56
 
 
 def test_lds_edge_tables_match_generator():

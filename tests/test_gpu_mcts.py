@@ -203,3 +203,42 @@ def test_branch_num_and_choose_below_the_root_on_the_engine(sds):
                 assert nat.choose(nat.root.make_move(c.last_move)).key() == py.choose(c).key()
         assert nat.root.key() == root_key == py.root.key()
         assert py.choose().last_move == nat.choose().last_move
+
+
+def test_simulation_mode_on_the_native_tree_on_the_engine(sds):
+    """boke.py --simulate (MCTS(no_sim=False), mcts.py:147-148,195-217) on the native tree with the HIP engine behind it: every
+    rollout ends in a policy playout evaluated position by position on the GPU.  (a) both nets, value_net_weight 0.5: N / Q /
+    V of the root's children equal the sequential restatement (oracle/mcts_ref.py) fed by the CPU oracle nets with the same
+    generator -- a draw would have to land within ~1e-6 of a boundary of the cumulative distribution to differ; (b) the policy
+    net alone (an engine without a ValueNet): Q only, V stays 0; (c) the same seed gives the same search, another seed another."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    from oracle.mcts_ref import RefMCTS
+    from oracle.oracle import OraclePolicy, OracleValue
+    P, V = OraclePolicy(sds[0]), OracleValue(sds[1])
+    pi, val = nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1])
+    ref = RefMCTS(P, V, expand_thresh=3, simulate=True, seed=21)
+    nat = NativeMCTS(Position(), pi, val, no_sim=False, expand_thresh=3, seed=21)
+    t0 = time.perf_counter()
+    nat.rollout(16)
+    dt = time.perf_counter() - t0
+    ref.rollout(16)
+    assert nat.value_net_weight == 0.5 and nat.N[nat.root] == 16
+    for mv, ck in ref.children[ref.root]:
+        child = nat.root.make_move(mv)
+        assert nat.N[child] == ref.N.get(ck, 0) and nat.Q[child] == ref.Q.get(ck, 0.0), mv
+        assert abs(nat.V[child] - ref.V.get(ck, 0.0)) < 1e-3
+    assert nat.choose().last_move == ref.choose()
+    gi = nat._pool.info(0)
+    print(f"simulation mode: 16 rollouts in {dt * 1e3:.0f} ms, {gi['n_policy_evals']} policy rows in {gi['n_requests']} requests")
+
+    only = [NativeMCTS(Position(), nnet.HipPolicyNet(sds[0]), None, no_sim=False, expand_thresh=3, seed=s) for s in (5, 5, 6)]
+    stats = []
+    for t in only:
+        t.rollout(24)
+        kids = [t.root.make_move(mv) for mv in t.child_stats()]
+        assert t.value_net_weight == 0.0 and t.root.value is None
+        assert sum(t.N[c] for c in kids) == 24 == t.N[t.root] and all(t.V[c] == 0 for c in kids)
+        assert sum(t.Q[c] for c in kids) == -t.Q[t.root] and abs(t.Q[t.root]) <= 24
+        stats.append({c.last_move: (t.N[c], t.Q[c]) for c in kids})
+    assert stats[0] == stats[1] and stats[0] != stats[2]

@@ -99,11 +99,15 @@ def test_launcher_accepts_the_reference_launchers_command_lines():
     assert ap.parse_args(["--simulate"]).simulate is True
 
 
-def test_simulation_mode_on_the_python_tree(nets):
+@pytest.mark.parametrize("native", [False, True])
+def test_simulation_mode_on_both_trees(nets, native):
     """--simulate = no_sim False (boke.py:42): rollouts are scored by a playout to the end of the game, the value net is not
     needed (mcts.py:59-60 only requires it in no-simulation mode)."""
+    from bokego_amd.gtp import NativeGTP
+    from bokego_amd.mcts_native import Position
     torch.manual_seed(0)
-    g = GTP(Go_MCTS(), nets[0], None, no_sim=False, time_lim=None, n_rollouts=6, expand_thresh=2)
+    cls, root = (NativeGTP, Position()) if native else (GTP, Go_MCTS())
+    g = cls(root, nets[0], None, no_sim=False, time_lim=None, n_rollouts=6, expand_thresh=2)
     g.running = True
     reply = g.send("genmove b")
     assert reply.startswith("= ") and reply.strip() not in ("=", "= resign")

@@ -221,14 +221,45 @@ def test_best_prior_children_only_is_the_same_search_on_one_tree(speculate):
     assert NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True))._pool is not None     # default: every child (EAGER_TOP = 0)
 
 
-def test_unsupported_modes_are_refused_not_ignored():
-    """kwargs of the reference's MCTS that the native tree does not implement (simulation mode, mcts.py:58; the degenerate
-    branch_num = 0, which gives every node an empty child set) raise instead of silently running a different search."""
-    with pytest.raises(NotImplementedError):
-        NativeMCTS(None, evaluator=object(), no_sim=False)
+def test_degenerate_branch_num_is_refused_not_ignored():
+    """branch_num = 0 gives every node an empty child set in the reference (mcts.py:189-190, 309-317): not a search the native
+    tree runs -- it raises instead of silently running a different one."""
     f = FakeNets()
     with pytest.raises(NotImplementedError):
         NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), branch_num=0)
+
+
+@pytest.mark.parametrize("with_value", [False, True])
+def test_simulation_mode_equals_the_sequential_restatement(with_value):
+    """MCTS(no_sim=False) (boke.py --simulate; mcts.py:147-148,195-217) on the native tree: N, Q and V of the root's children
+    equal oracle/mcts_ref.py's sequential restatement rollout for rollout (same generator, same draws), with the policy net
+    alone (value_net_weight 0) and with both nets (0.5), over three moves; the tree's own playout nodes do not pile up."""
+    from oracle.mcts_ref import RefMCTS
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = (lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)) if with_value else None  # noqa: E731
+    ref = RefMCTS(pol, val, expand_thresh=4, simulate=True, seed=11)
+    nat = NativeMCTS(Position(), _Wrap(pol), _Wrap(val, True) if with_value else None, no_sim=False, expand_thresh=4, seed=11)
+    assert nat.value_net_weight == (0.5 if with_value else 0.0) == ref.w
+    for ply in range(3):
+        ref.rollout(60); nat.rollout(60)
+        rk = ref.root
+        for mv, ck in ref.children[rk]:
+            child = nat.root.make_move(mv)
+            assert nat.N[child] == ref.N.get(ck, 0), (ply, mv)
+            assert nat.Q[child] == ref.Q.get(ck, 0.0), (ply, mv)
+            assert abs(nat.V[child] - ref.V.get(ck, 0.0)) < 1e-5
+        if not with_value:
+            assert nat.root.value is None and nat.V[nat.root] == 0
+        n = ref.N[rk]
+        want = (((1 - ref.w) * ref.Q[rk] + ref.w * ref.V.get(rk, 0.0)) / n + 1) / 2
+        assert nat.N[nat.root] == n and abs(nat.winrate() - want) < 1e-6
+        nodes_before = (nat._pool.info(0)["n_nodes"], len(ref.state))
+        a, b = ref.choose(), nat.choose()
+        assert a == b.last_move
+    # playout positions outside the tree are dropped when their playout ends: the tree holds what expansions interned
+    assert nodes_before[0] == nodes_before[1]
+    assert any(abs(q) > 0 for q in ref.Q.values())
 
 
 @pytest.mark.parametrize("speculate", [0, 8])

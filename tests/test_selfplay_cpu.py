@@ -425,3 +425,37 @@ def test_in_batch_deduplication_plays_the_same_games():
         assert local["rows_sent"] == sent < local["rows_requested"] == base[2]
     # the games share their openings (two sampled plies apart): a part of the rows is saved
     assert out["dedup"][2] < 0.95 * base[2]
+
+
+def test_simulation_mode_pools_do_not_depend_on_grouping_threads_or_record_path():
+    """bk_search_params.simulate (MCTS(no_sim=False), mcts.py:147-148,195-217) in self-play pools: what a game plays depends on
+    its seed alone -- one game per pool, four games on three threads, position records with in-batch de-duplication and with
+    branch_num all give the same games per seed; the playouts' own nodes never outlive them."""
+    f = FakeNets()
+    seeds = [3, 4, 5, 6]
+
+    def play(groups, threads, records=False, **kw):
+        prm = selfplay.search_params(rollouts=12, max_turns=16, expand_thresh=3, simulate=1, value_weight=0.5, record_visits=1, **kw)
+        out = {}
+        for grp in groups:
+            pool = selfplay.GamePool(grp, prm, cap=256, threads=threads)
+            if records:
+                pool.set_dedup(True)
+                ev = selfplay.RecordEvaluator(f.policy, f.value)
+            else:
+                ev = selfplay.CallableEvaluator(f.policy, f.value)
+            selfplay.run_pools([pool], ev)
+            for i, sd in enumerate(grp):
+                assert pool.info(i)["done"] == 1
+                out[sd] = (pool.moves(i), [pool.visits(i, ply) for ply in range(len(pool.moves(i)))])
+            pool.close()
+        return out
+
+    alone = play([[s] for s in seeds], 1)
+    assert play([seeds], 3) == alone
+    assert play([seeds[:2], seeds[2:]], 2, records=True) == alone
+    assert len({repr(rc) for _, rc in alone.values()}) > 1            # the seeds do draw different playouts
+    few = play([[s] for s in seeds], 1, branch_num=6)
+    assert play([seeds], 3, branch_num=6) == few and few != alone
+    with_prune = play([seeds], 2, prune=1)
+    assert {s: m for s, (m, _) in with_prune.items()} == {s: m for s, (m, _) in alone.items()}
