@@ -11,6 +11,8 @@ reference's observable dicts -- `tree.N[node]`, `tree.V[node]`, `tree.Q[node]`, 
 (mcts.py:46-52; GTP.analyze reads `self.N[n]`, gtp.py:386,395) -- are read-only mapping views that
 look a node up by its position in the native tree; `rollout(n, analyze_dict)` fills the caller's dict
 with the variations exactly as mcts.py:143-147 does, so `analyze` runs on the native search.
+Every keyword of the reference's MCTS runs here: expand_thresh, branch_num, exploration_weight, noise_weight, and no_sim=False
+with value_net_weight (simulation mode: policy playouts scored into Q; value_net may then be None) -- see bokego_tree.h.
 """
 import ctypes
 from collections.abc import Mapping
