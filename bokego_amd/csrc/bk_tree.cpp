@@ -30,7 +30,7 @@
 
 namespace {
 
-// 56 bytes: the search (select / backprop) walks these and nothing else; the 192-byte position of node i is poses[i]
+// 48 bytes: the search (select / backprop) walks these and nothing else; the 192-byte position of node i is poses[i]
 // (read when a node is interned, expanded or sent for evaluation).  A node's children are interned together, so their
 // statistics are mostly neighbours in memory.  Measured on a synthetic 72-child select (tools/micro/select_bench.cpp):
 // 232-byte nodes with two divisions per child 350 ns, these nodes 240 ns, + the cached average 185 ns.
@@ -45,7 +45,6 @@ struct TNode {
     int kids_off = 0, n_kids = 0;
     int prior_off = -1;
     int mv = BK_NO_MOVE;
-    double Q = 0.0;    // summed playout rewards (MCTS.Q[node]); stays 0 unless prm.simulate
 };
 
 enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_PLAYOUT, S_WAIT_LEAF, S_CHOOSE, S_DONE, S_IDLE };
@@ -90,6 +89,7 @@ struct Game {
     bk_search_params prm;
     std::vector<TNode> nodes;
     std::vector<bk_pos> poses;          // parallel to nodes
+    std::vector<double> Qs;             // parallel to nodes when prm.simulate: summed playout rewards (MCTS.Q[node]); else empty
     std::vector<int> kid_ids;
     std::vector<double> priors;
     // position -> node id: open addressing over a flat array (power-of-two size, linear probing, -1 = empty).  No per-bucket
@@ -100,7 +100,7 @@ struct Game {
     std::vector<int> sc_remap, sc_order, sc_kids, sc_ids, sc_w;
     std::vector<TNode> sc_nodes;
     std::vector<bk_pos> sc_poses;
-    std::vector<double> sc_priors;
+    std::vector<double> sc_priors, sc_Q;
     int root = -1;
     State state = S_INIT;
     int remaining = 0;
@@ -159,6 +159,7 @@ struct Game {
         n.terminal = (p.turn > prm.max_turns || p.last_move == BK_PASS) ? 1 : 0;  // mcts.py:362-364
         nodes.push_back(n);
         poses.push_back(p);
+        if (prm.simulate) Qs.push_back(0.0);
         table_insert((int)nodes.size() - 1);
         return (int)nodes.size() - 1;
     }
@@ -428,6 +429,7 @@ struct Game {
         }
         nodes.resize((size_t)po_mark);
         poses.resize((size_t)po_mark);
+        Qs.resize((size_t)po_mark);
         po_priors.clear();
         po_mark = -1;
     }
@@ -458,15 +460,16 @@ struct Game {
     }
 
     void backprop() {  // mcts.py:208-217
-        if (prm.simulate || !prm.use_value) {
+        if (prm.simulate || !prm.use_value || prm.value_weight != 1.0) {
             double v = (double)nodes[path.back()].value, r = (double)po_reward;
             const double w = prm.value_weight;
             for (int i = (int)path.size() - 1; i >= 0; --i) {
                 TNode& n = nodes[path[i]];
+                double q = 0.0;
                 n.N += 1;
-                if (prm.simulate) { n.Q += r; r = -r; }
+                if (prm.simulate) { q = (Qs[path[i]] += r); r = -r; }
                 if (prm.use_value) { n.V += v; v = -v; }
-                n.avg = ((1 - w) * n.Q + w * n.V) / (double)n.N;
+                n.avg = ((1 - w) * q + w * n.V) / (double)n.N;
             }
             return;
         }
@@ -531,10 +534,12 @@ struct Game {
         std::vector<bk_pos>& npos = sc_poses;
         std::vector<int>& nk = sc_kids;
         std::vector<double>& np = sc_priors;
+        std::vector<double>& nq = sc_Q;
         nn.clear();
         npos.clear();
         nk.clear();
         np.clear();
+        nq.clear();
         for (int old : order) {
             TNode n = nodes[old];
             const int off = (int)nk.size();
@@ -547,7 +552,9 @@ struct Game {
             }
             nn.push_back(n);
             npos.push_back(poses[old]);
+            if (prm.simulate) nq.push_back(Qs[old]);
         }
+        Qs.swap(nq);
         nodes.swap(nn);       // the old arrays become next time's scratch
         poses.swap(npos);
         kid_ids.swap(nk);
@@ -1501,7 +1508,7 @@ int bk_pool_node_q(const bk_pool* p, int g, int id, double* q) {
     if (g < 0 || g >= (int)p->games.size() || !q) return -1;
     const Game& gm = p->games[g];
     if (id < 0 || id >= (int)gm.nodes.size()) return -1;
-    *q = gm.nodes[id].Q;
+    *q = gm.prm.simulate ? gm.Qs[id] : 0.0;
     return 0;
 }
 

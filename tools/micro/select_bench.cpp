@@ -7,7 +7,7 @@
 #include <cstdint>
 #include <vector>
 #include <random>
-#include <emmintrin.h>
+#include <immintrin.h>
 struct Pos { char b[192]; };
 struct Fat { Pos pos; double V = 0; int N = 0; float value = 0; uint8_t f[4]; int ko = 0, nk = 0, po = -1, mv = 0; };
 struct Slim { double V = 0; double avg = 0; int N = 0; int mv = 0; };
@@ -62,6 +62,32 @@ int sel_sse(const std::vector<Slim>& nodes, const int* kids, int n, const double
     }
     return best;
 }
+// gather (N, avg, prior) of the children into arrays, scores four at a time (vdivpd ymm), first maximum in a scalar pass:
+// the same IEEE operations per child in the same order as sel_avg, so the same bits and the same choice.  Round 4, on the GPU
+// box's EPYC 9575F: cached avg (shipped) 91 ns per 72-child select = 1.26 ns per child, divpd xmm 88 ns, this 111 ns -- the
+// scalar loop already runs at the divider's pace and the staging costs more than the packed division saves.  Not adopted.
+__attribute__((target("avx2"))) int sel_avx2(const std::vector<Slim>& nodes, const int* kids, int n, const double* prior, double c) {
+    alignas(32) int nn[96];
+    alignas(32) double av[96], pr[96], sc[96];
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const Slim& k = nodes[kids[i]];
+        nn[i] = 1 + k.N; av[i] = k.avg; pr[i] = prior[k.mv];
+        total += k.N;
+    }
+    for (int i = n; i < ((n + 3) & ~3); ++i) { nn[i] = 1; av[i] = 0; pr[i] = 0; }
+    if (!total) total = 1;
+    const __m256d sq = _mm256_set1_pd(std::sqrt((double)total)), cc = _mm256_set1_pd(c);
+    for (int i = 0; i < n; i += 4) {
+        const __m256d num = _mm256_mul_pd(_mm256_mul_pd(cc, _mm256_load_pd(pr + i)), sq);
+        const __m256d den = _mm256_cvtepi32_pd(_mm_load_si128((const __m128i*)(nn + i)));
+        _mm256_store_pd(sc + i, _mm256_sub_pd(_mm256_div_pd(num, den), _mm256_load_pd(av + i)));
+    }
+    int best = -1; double bs = 0;
+    for (int i = 0; i < n; ++i)
+        if (best < 0 || sc[i] > bs) { best = kids[i]; bs = sc[i]; }
+    return best;
+}
 int main() {
     const int NK = 72, NPAR = 200;
     std::mt19937 rng(1);
@@ -86,5 +112,6 @@ int main() {
         run("slim nodes, 2 divisions", [&](const int* k) { return sel_base(slim, k, NK, prior.data(), 4.0); });
         run("slim nodes, cached avg", [&](const int* k) { return sel_avg(slim, k, NK, prior.data(), 4.0); });
         run("slim, cached avg, divpd", [&](const int* k) { return sel_sse(slim, k, NK, prior.data(), 4.0); });
+        run("slim, cached avg, avx2", [&](const int* k) { return sel_avx2(slim, k, NK, prior.data(), 4.0); });
     }
 }
