@@ -60,3 +60,10 @@ print(f"moves {n}  ms/move mean {1e3 * sum(per_move) / n:.3f}  min {1e3 * min(pe
 print(f"evaluator calls {len(lat)} = {len(lat) / n:.1f} per move; in-evaluator time {1e3 * sum(lat) / n:.3f} ms/move; "
       f"per call median {1e6 * sorted(lat)[len(lat) // 2]:.0f} us  p10 {1e6 * sorted(lat)[len(lat) // 10]:.0f} us")
 print("batch (boards, policy rows) -> calls:", dict(sizes.most_common(12)))
+bands = Counter()
+for (rows, npol), c in sizes.items():
+    tasks = rows + npol
+    bands["<=21" if tasks <= 21 else "22-32" if tasks <= 32 else "33-42" if tasks <= 42 else "43-64" if tasks <= 64 else
+          "65-85" if tasks <= 85 else "86-128" if tasks <= 128 else ">128"] += c
+print("requests by network tasks (the launch forms' ranges: 12 / 8 / 6 / 4 / 3 / 2 / 1 CUs per board):",
+      {k: bands[k] for k in ("<=21", "22-32", "33-42", "43-64", "65-85", "86-128", ">128")})
