@@ -588,11 +588,20 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BK_SELFPLAY_BACKEND=gloo BK_SELFPLAY_DEVICE=0: a rehearsal of the N-rank run on ONE card (RCCL refuses two ranks on one
+    # GPU): the same sharding, the same all-reduce of the statistics, over gloo on host tensors
+    backend = os.environ.get("BK_SELFPLAY_BACKEND", "nccl")
+    if "BK_SELFPLAY_DEVICE" in os.environ:
+        local_rank = int(os.environ["BK_SELFPLAY_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    on_gpu = torch.device("cuda", local_rank) if backend == "nccl" else None
 
     def load(path, default):
         path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", default)
@@ -610,11 +619,11 @@ def main():
         gids = shard_game_ids(args.games, r, w)
     local, total = self_play(ev, n_games=args.games, rollouts=args.rollouts, rank=rank, world=world,
                              max_turns=args.max_turns, cap=args.max_batch, threads=args.threads, n_pools=args.pools,
-                             reduce_device=torch.device("cuda", local_rank), record_visits=int(bool(args.out)), gids=gids,
+                             reduce_device=on_gpu, record_visits=int(bool(args.out)), gids=gids,
                              eager_top=args.eager_top, task_cap=args.task_cap)
     secs = local["seconds"]
     if world > 1:
-        t = torch.tensor([secs], dtype=torch.float64, device="cuda")
+        t = torch.tensor([secs], dtype=torch.float64, device=on_gpu or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
     if rank == 0:

@@ -121,6 +121,27 @@ def test_native_comm_world2(tmp_path):
     assert [r["rank"] for r in res] == [0, 1] and all(r["ok"] and r["world"] == 2 for r in res)
 
 
+def test_self_play_cli_two_ranks_on_one_card_over_gloo():
+    """`python -m bokego_amd.selfplay` as two ranks (the torch.distributed.run environment) sharing the box's one GPU over
+    gloo (BK_SELFPLAY_BACKEND / BK_SELFPLAY_DEVICE: RCCL refuses two ranks on one card): the sharding gid % world, the
+    all-reduce of the statistics and the max-over-ranks time are the N-GPU run's; the reduced statistics equal one rank's."""
+    import json
+    import os
+    from bokego_amd import selfplay
+    from bokego_amd.bkw import load_bkw
+    from bokego_amd.engine import LeafEngine
+    from conftest import GOLDEN
+    outs = _spawn_ranks(["-m", "bokego_amd.selfplay", "--games", "16", "--rollouts", "60", "--max-turns", "30"], 2,
+                        {"BK_SELFPLAY_BACKEND": "gloo", "BK_SELFPLAY_DEVICE": "0"})
+    two = json.loads(outs[0].strip().splitlines()[-1])
+    assert not [ln for ln in outs[1].splitlines() if ln.lstrip().startswith("{")]     # rank 0 alone reports
+    eng = LeafEngine(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw")), max_batch=8192)
+    _, one = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=16, rollouts=60, max_turns=30, cap=8192)
+    eng.close()
+    assert two["n_gpus"] == 2 and two["games"] == 16 == one["games"] and two["plies"] == one["plies"]
+    assert two["black_wins"] == one["black_wins"] and two["leaf_evals"] == one["value_evals"]
+
+
 @pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
 def test_torch_distributed_nccl_world2_self_play_shards():
     """bokego_amd.selfplay as two ranks over torch.distributed's nccl (= RCCL) backend: the reduced statistics of a
