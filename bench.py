@@ -897,7 +897,8 @@ def main():
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
               "search": "an expansion evaluates its best-prior children only (bk_search_params.eager_top), the rest when a rollout "
-                        "reaches it: the same 512 games as with every child evaluated (rounds 1-2), 3.4 M -> 0.7 M evaluations"}
+                        "reaches it: the same 512 games as with every child evaluated (rounds 1-2), 3.4 M -> 0.6-0.7 M evaluations "
+                        "(children_evaluated_per_expansion: fp32 2 from 192 games per rank, else 4; f16x2 6)"}
         # untimed: a small generation first (the pools' worker threads exist, the allocator and the caches are warm)
         selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=min(64 * world, args.selfplay_games), rollouts=50, rank=rank, world=world,
                            cap=8192, threads=threads, reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
@@ -910,7 +911,7 @@ def main():
             secs = reduce_max(local["seconds"])
             sp[prec] = {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
                         "plies": total["plies"], "value_evals": total["value_evals"], "value_evals_per_s": total["value_evals"] / secs,
-                        "children_evaluated_per_expansion": selfplay.EAGER_TOP.get(prec),
+                        "children_evaluated_per_expansion": selfplay.default_eager_top(prec, len(selfplay.shard_game_ids(args.selfplay_games, rank, world))),
                         "black_wins": total["black_wins"], "stats_allreduce_ms": local["allreduce_s"] * 1e3,
                         "first_move_hist_sum": int(sum(total["first_move_hist"]))}
         eng.set_precision(args.precision)

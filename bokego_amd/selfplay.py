@@ -407,7 +407,21 @@ def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None)
 # round of workgroups per step), f16x2 59.3 k at 4 children and two pools (8 children / three pools: 53.0 k); and with fp32
 # batches held to whole rounds of workgroups (task_cap below): fp32 3: 32.3 k | 4: 32.9 k | 5: 30.8 k | 6: 28.8 k | 8: 25.2 k;
 # f16x2 3: 55.4 k | 4: 58.9 k | 6: 62.6 k.
+# Round 4 (the one-board workgroups got faster, 334 -> 298 us, and equal rows of a batch travel once): with TWO children per
+# expansion a 256-game pool asks for ~480 tasks per step -- one round of 2-board workgroups (534 us) instead of one of 3-board
+# ones four fifths full (750 us) -- and the generation needs 17 % fewer evaluations (0.58 M): fp32 512 games 34.6 k -> 36.6 k
+# games/min, 256 games (a rank's share at 2 ranks) 27.6 k -> 31.5 k; 128 games the same (23.3 k / 23.5 k), 64 games slower
+# (20.9 k -> 19.8 k: there a step is a cooperative launch whose time hardly depends on its size, and two children mean more
+# steps).  So fp32 evaluates 2 children from 192 games per rank, else 4 (profiles/r04_eager_probe.txt); 3 is worse than both
+# everywhere (its batches straddle the rounds).
 EAGER_TOP = {"f32": 4, "f16x2": 6}
+EAGER_TOP_F32_MANY_GAMES = (192, 2)       # from this many games per rank: this many children
+
+
+def default_eager_top(precision, n_games_here):
+    if precision == "f32" and n_games_here >= EAGER_TOP_F32_MANY_GAMES[0]:
+        return EAGER_TOP_F32_MANY_GAMES[1]
+    return EAGER_TOP.get(precision, 8)
 # In-batch de-duplication of the pools' requests (bk_pool_set_dedup; the in-batch part of the reference's class-level memo,
 # mcts.py:41-44).  Measured on one MI355X, 512 games x 400 rollouts/move, the same games move for move (tools/dedup_ab.py,
 # profiles/r04_dedup.txt): 7.1 % of the rows are byte-for-byte repeats of another game's row in the same batch (all of them in
@@ -432,7 +446,7 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
     if eager_top is None:
-        eager_top = EAGER_TOP.get(precision, 8)
+        eager_top = default_eager_top(precision, len(gids))
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
                         eager_top=eager_top)
@@ -450,8 +464,13 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         # (~3 tasks per game and step with 4 children per expansion).  f16x2 steps are host-bound: no limit.
         # (minus 4: policy rows and value rows are rounded up to whole 3-board workgroups separately, and 257 workgroups are
         # two rounds -- rocprofv3 showed 605 of 1,160 launches at exactly 768 tasks taking the 1.0 ms three-round one-board form)
-        per_round = 3 * getattr(getattr(evaluator, "engine", None), "n_cu", 256)
-        task_cap = per_round * max(1, round(3.0 * max(len(part) for part in parts) / per_round)) - 4 if (precision == "f32" and eager_top) else 0
+        n_cu = getattr(getattr(evaluator, "engine", None), "n_cu", 256)
+        per_round, biggest = 3 * n_cu, max((len(part) for part in parts), default=0)     # (a rank may have no game at all)
+        if precision == "f32" and 0 < eager_top <= 2:
+            # ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups (256 / 512 / 768 tasks on 256 CUs)
+            task_cap = n_cu * max(1, round(2.0 * biggest / n_cu)) - 4
+        else:
+            task_cap = per_round * max(1, round(3.0 * biggest / per_round)) - 4 if (precision == "f32" and eager_top) else 0
     if dedup is None:
         dedup = os.environ["BK_DEDUP"] == "1" if "BK_DEDUP" in os.environ else DEDUP.get(precision, False)
     for pool in pools:

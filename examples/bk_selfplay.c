@@ -63,6 +63,10 @@ int main(int argc, char **argv) {
         const char *pe = getenv("BK_PRECISION");
         prm.eager_top = (pe && strcmp(pe, "f16x2") == 0) ? 6 : 4;
     }
+    int mine_n = 0;
+    for (int g = rank; g < n_games; g += world) ++mine_n;
+    const int f32 = !(getenv("BK_PRECISION") && strcmp(getenv("BK_PRECISION"), "f16x2") == 0);
+    if (f32 && mine_n >= 192) prm.eager_top = 2;   /* fp32 from 192 games per rank: two children (selfplay.py, EAGER_TOP) */
 
     /* this rank's games, dealt to the pools round-robin */
     slot_t s[NPOOLS];
@@ -85,8 +89,13 @@ int main(int argc, char **argv) {
         {
             const char *pe2 = getenv("BK_PRECISION");
             if (!(pe2 && strcmp(pe2, "f16x2") == 0)) {
-                int rounds = (3 * k + 384) / 768;
-                bk_pool_set_task_cap(s[i].pool, 768 * (rounds < 1 ? 1 : rounds) - 4);
+                if (prm.eager_top <= 2) {          /* ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups */
+                    int rounds = (2 * k + 128) / 256;
+                    bk_pool_set_task_cap(s[i].pool, 256 * (rounds < 1 ? 1 : rounds) - 4);
+                } else {
+                    int rounds = (3 * k + 384) / 768;
+                    bk_pool_set_task_cap(s[i].pool, 768 * (rounds < 1 ? 1 : rounds) - 4);
+                }
                 bk_pool_set_dedup(s[i].pool, 1);   /* equal records of one batch travel once: +4 % where the GPU is the limit */
             }
         }
