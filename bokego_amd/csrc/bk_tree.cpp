@@ -47,6 +47,7 @@ struct TNode {
     int mv = BK_NO_MOVE;
 };
 
+constexpr int kStepTrim = 4;   // children an expansion leaves to later requests to stay within a step of prm.request_steps
 enum State { S_INIT, S_ROOT_EXPAND, S_WAIT_ROOT, S_ROOT_READY, S_SEARCH, S_PLAYOUT, S_WAIT_LEAF, S_CHOOSE, S_DONE, S_IDLE };
 
 struct Rng {  // xoshiro256** seeded by splitmix64: per-game stream, independent of how games are sharded
@@ -246,8 +247,20 @@ struct Game {
             // with unknown priors (the policy row travels in this very request) nothing says which child the search wants
             // first: every child goes now.  With known priors (the node was evaluated ahead) the tail may wait.
             const bool may_wait = prm.request_tasks > 0 && nodes[id].has_prior;
-            for (int c : wanting(kidv, id)) {
-                if (!may_wait || (fits(1) && room_for_rows(1))) req_value.push_back(c);
+            const std::vector<int> w = wanting(kidv, id);
+            // An expansion with unknown priors that comes out just over a step of the request sizes -- 79 children + the policy
+            // row = 81 tasks, where the engine's launch gives a board 3 CUs up to 80 tasks and 2 from 81 (135 -> 174 us) -- leaves
+            // its last children (move order: nothing says which matter) to later requests, like the overflow of any other
+            // expansion; one of them is needed before it has travelled in about one case in fifty.
+            size_t keep = w.size();
+            if (!may_wait && prm.request_tasks > 0) {
+                const int need = request_tasks() + (int)w.size();
+                for (int st : prm.request_steps)
+                    if (st > 0 && need > st && need - st <= kStepTrim && need - st < (int)w.size()) keep = w.size() - (size_t)(need - st);
+            }
+            for (size_t i = 0; i < w.size(); ++i) {
+                const int c = w[i];
+                if (i < keep && (!may_wait || (fits(1) && room_for_rows(1)))) req_value.push_back(c);
                 else spill.push_back(c);
             }
         }

@@ -65,5 +65,10 @@ for (rows, npol), c in sizes.items():
     tasks = rows + npol
     bands["<=21" if tasks <= 21 else "22-32" if tasks <= 32 else "33-42" if tasks <= 42 else "43-64" if tasks <= 64 else
           "65-85" if tasks <= 85 else "86-128" if tasks <= 128 else ">128"] += c
+over = Counter()
+for (rows, npol), c in sizes.items():
+    if 60 <= rows + npol <= 90:
+        over[rows + npol] += c
+print("requests of 60..90 tasks, by tasks:", dict(sorted(over.items())))
 print("requests by network tasks (the launch forms' ranges: 12 / 8 / 6 / 4 / 3 / 2 / 1 CUs per board):",
       {k: bands[k] for k in ("<=21", "22-32", "33-42", "43-64", "65-85", "86-128", ">128")})
