@@ -59,6 +59,11 @@ print("speculate =", os.environ.get("BK_SPECULATE", "(default)"), " value evals"
 print(f"moves {n}  ms/move mean {1e3 * sum(per_move) / n:.3f}  min {1e3 * min(per_move):.3f}  max {1e3 * max(per_move):.3f}")
 print(f"evaluator calls {len(lat)} = {len(lat) / n:.1f} per move; in-evaluator time {1e3 * sum(lat) / n:.3f} ms/move; "
       f"per call median {1e6 * sorted(lat)[len(lat) // 2]:.0f} us  p10 {1e6 * sorted(lat)[len(lat) // 10]:.0f} us")
+import ctypes  # noqa: E402
+ph = (ctypes.c_double * 3)()
+tree._lib.bk_pool_phase_seconds(tree._pool._h, ph)
+print(f"native tree per move (whole run incl. warm-up): advance {1e3 * ph[0] / n:.3f} ms, emit {1e3 * ph[1] / n:.3f} ms, deliver {1e3 * ph[2] / n:.3f} ms; "
+      f"outside the evaluator {1e3 * (sum(per_move) - sum(lat)) / n:.3f} ms/move")
 print("batch (boards, policy rows) -> calls:", dict(sizes.most_common(12)))
 bands = Counter()
 for (rows, npol), c in sizes.items():

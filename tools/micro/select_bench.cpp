@@ -88,7 +88,24 @@ __attribute__((target("avx2"))) int sel_avx2(const std::vector<Slim>& nodes, con
         if (best < 0 || sc[i] > bs) { best = kids[i]; bs = sc[i]; }
     return best;
 }
-int main() {
+// an unvisited child (N = 0, avg = +0.0) scores -0.0 + c p sq / 1.0 = c p sq exactly: no division for it.  In a real tree ~70 of a
+// node's ~75 children are unvisited (main() below draws N accordingly when run with an argument).  EPYC 9575F, that mix: 90.8 ->
+// 83.4 ns per select; in the tree 0.385 -> 0.354 ms of search per 1600-rollout move.  Adopted (csrc/bk_tree.cpp, select).
+int sel_zero(const std::vector<Slim>& nodes, const int* kids, int n, const double* prior, double c) {
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += nodes[kids[i]].N;
+    if (!total) total = 1;
+    const double sq = std::sqrt((double)total);
+    int best = -1; double bs = 0;
+    for (int i = 0; i < n; ++i) {
+        const Slim& k = nodes[kids[i]];
+        const double e = c * prior[k.mv] * sq;
+        const double s = k.N == 0 ? e : -k.avg + (e / (double)(1 + k.N));
+        if (best < 0 || s > bs) { best = kids[i]; bs = s; }
+    }
+    return best;
+}
+int main(int argc, char**) {
     const int NK = 72, NPAR = 200;
     std::mt19937 rng(1);
     std::vector<Fat> fat(NPAR * NK + 1); std::vector<Slim> slim(NPAR * NK + 1);
@@ -96,7 +113,8 @@ int main() {
     for (auto& p : prior) p = (rng() % 1000) / 40000.0;
     for (int i = 0; i < NPAR * NK; ++i) {
         kids[i] = i + 1;
-        int N = rng() % 50; double V = ((int)(rng() % 2000) - 1000) / 1000.0 * N;
+        int N = rng() % 50; if (argc > 1 && rng() % 72 >= 5) N = 0;   // with an argument: 5 of 72 children visited, as in a search
+        double V = ((int)(rng() % 2000) - 1000) / 1000.0 * N;
         fat[i + 1].N = N; fat[i + 1].V = V; fat[i + 1].mv = i % 81;
         slim[i + 1].N = N; slim[i + 1].V = V; slim[i + 1].mv = i % 81; slim[i + 1].avg = N ? V / N : 0;
     }
@@ -112,6 +130,7 @@ int main() {
         run("slim nodes, 2 divisions", [&](const int* k) { return sel_base(slim, k, NK, prior.data(), 4.0); });
         run("slim nodes, cached avg", [&](const int* k) { return sel_avg(slim, k, NK, prior.data(), 4.0); });
         run("slim, cached avg, divpd", [&](const int* k) { return sel_sse(slim, k, NK, prior.data(), 4.0); });
+        run("slim, cached avg, N=0 shortcut", [&](const int* k) { return sel_zero(slim, k, NK, prior.data(), 4.0); });
         run("slim, cached avg, avx2", [&](const int* k) { return sel_avx2(slim, k, NK, prior.data(), 4.0); });
     }
 }
