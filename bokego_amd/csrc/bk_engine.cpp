@@ -631,8 +631,10 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
     // "cooperative form").  A workgroup that gives up waiting for its peers raises word 1 of the slot's flag block, which
     // travels to the host with the outputs: bk_wait then redoes the request with the one-CU form.
-    if (const int slices = (allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag &&
-                            !getenv("BK_FORCE_NB")) ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0) {
+    const bool coop_ok = allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag && !getenv("BK_FORCE_NB");
+    int coop_form = coop_ok ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0;
+    if (coop_ok && !coop_form) coop_form = bk_coop3_form(a.B_policy, a.B_value, e->n_cu);   // three boards on 2 / 4 CUs
+    if (const int slices = coop_form) {
         a.coop_xchg = e->d_coop_xchg;
         a.coop_sync = e->d_coop_sync;
         a.coop_err = d_flag + 1;
@@ -740,7 +742,8 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     std::memset(e->h_redo, 0, BK_DEV_FLAGS * sizeof(unsigned int));
     TRY_CREATE(hipHostGetDevicePointer((void**)&e->h_redo_dev, e->h_redo, 0));
     {
-        const size_t xb = (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), sb = (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int);
+        static_assert(BK_COOP_XCHG_BYTES >= (size_t)BK_COOP_MAX_TASKS * 2 * 81 * 128 * sizeof(float), "one buffer for both cooperative forms");
+        const size_t xb = BK_COOP_XCHG_BYTES, sb = (size_t)BK_COOP_SYNC_WORDS * sizeof(unsigned int);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_xchg, xb));
         e->dev_allocs.push_back(e->d_coop_xchg);
         TRY_CREATE(hipMalloc((void**)&e->d_coop_sync, sb));
@@ -1149,7 +1152,9 @@ int bk_engine_max_batch(bk_engine* e) { return e ? e->max_batch : BK_ERR_ARG; }
 int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int* boards_per_workgroup) {
     if (n_policy < 0 || n_value < 0 || n_cu <= 0 || (precision != BK_PRECISION_F32 && precision != BK_PRECISION_F16X2)) return BK_ERR_ARG;
     if (boards_per_workgroup) *boards_per_workgroup = bk_pick_nb(n_policy, n_value, n_cu, precision);
-    return precision == BK_PRECISION_F32 ? bk_coop_slices(n_policy + n_value, n_cu) : 0;
+    if (precision != BK_PRECISION_F32) return 0;
+    if (const int slices = bk_coop_slices(n_policy + n_value, n_cu)) return slices;
+    return bk_coop3_form(n_policy, n_value, n_cu);      // BK_COOP3_FORM_2 / _4 (102 / 104): three boards on 2 / 4 CUs
 }
 
 int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* executed_mfma_flop, double* algorithmic_flop,
@@ -1162,6 +1167,9 @@ int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* 
     if (n_policy + n_value > 0) {
         if (const int slices = cooperative ? bk_coop_slices(n_policy + n_value, n_cu) : 0) {
             exe = bk_coop_mfma_flop_per_task(slices) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
+            launches = 1;
+        } else if (cooperative && bk_coop3_form(n_policy, n_value, n_cu)) {
+            exe = bk_mfma_flop_per_workgroup(3) * ((n_policy + 2) / 3 + (n_value + 2) / 3);   // the 3-board tile set, shared by 2 / 4 CUs
             launches = 1;
         } else {
             const LaunchPlan pl = plan_launch(n_policy, n_value, n_cu, BK_PRECISION_F32);

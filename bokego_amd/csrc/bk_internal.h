@@ -97,5 +97,13 @@ double bk_mfma_flop_per_workgroup(int nb);   // fp32 kernel: executed MFMA FLOP 
 #define BK_COOP_POISON_WORD (BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE)
 #define BK_COOP_SYNC_WORDS (BK_COOP_POISON_WORD + BK_COOP_SYNC_STRIDE)
 int bk_coop_slices(int tasks, int n_cu);   // 0: not a cooperative case
+// three boards of one net on 2 / 4 CUs (bk_kernels.hip, bk_leaf_eval_coop3_kernel): form codes beside the one-board form's 2..12
+#define BK_COOP3_FORM_2 102
+#define BK_COOP3_FORM_4 104
+#define BK_COOP3_MAX_GROUPS 128                       // 128 groups x 2 CUs = the chip
+#define BK_COOP3_FORM_4_MAX 192                       // tasks: up to here four CUs per three boards ...
+#define BK_COOP3_FORM_2_MAX 384                       // ... and two up to here (beyond: whole-board workgroups)
+#define BK_COOP_XCHG_BYTES ((size_t)BK_COOP3_MAX_GROUPS * 2 * 243 * 128 * 4)   // the exchange buffer serves both forms
+int bk_coop3_form(int B_policy, int B_value, int n_cu);   // 0 / BK_COOP3_FORM_2 / BK_COOP3_FORM_4
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -961,6 +961,199 @@ hipError_t launch_coop(const bk_eval_args& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- three boards on SC CUs ------------------------------------------------------------------------------------------------
+// Between the whole-board forms there are gaps: 129..256 tasks take a round of one-board workgroups (298 us) and 257..512 one
+// of two-board workgroups (530 us) however far they are from filling it -- and the requests of lock-step self-play sit in
+// those gaps (a 256-game pool asks for ~370 tasks per step, a 128-game one for ~185).  Here SC = 2 or 4 workgroups on SC CUs
+// share THREE boards of one net on the 3-board tile set (Tiles<3>: 63 of 72 tile-taps): each computes 128 / SC output channels
+// of all 243 points in every layer, publishes them (L2), meets its peers at the group's counter and fetches theirs into its
+// own LDS image -- the exchange of the one-board cooperative form above, with its coherence, placement and bounded poll.  1.5
+// boards per CU (up to 384 tasks) and 0.75 (up to 192).  Every dot product runs in the same order on the same instruction as in
+// every other form: bit-identical results.
+template <int SC>
+struct Coop3Tiles {
+    static_assert(SC == 2 || SC == 4, "three boards on two or four CUs");
+    static constexpr int S = SC, WM = 2, RT = 8, CTW = 1;
+    static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
+    static constexpr int NW = WM * CT, THREADS = 64 * NW;
+    static constexpr int A0 = 1, A1 = 6, X0 = 0, X1 = -1, Y0a = 6, Y0b = 8, Y1 = -1;   // as Tiles<3>
+    static constexpr bool WM_EDGES = true, DB2 = true;
+    static constexpr int RING = 4;
+    static constexpr int XCHG_FLOATS = 2 * 243 * 128;   // per group: two layer parities
+};
+static_assert(Coop3Tiles<2>::XCHG_FLOATS * 4 * BK_COOP3_MAX_GROUPS <= BK_COOP_XCHG_BYTES, "exchange buffer");
+
+template <int SC>
+__global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_kernel(const bk_eval_args a) {
+    using G = Geo<3>;
+    using F = Coop3Tiles<SC>;
+    constexpr int THREADS = F::THREADS, RT = F::RT, S = F::S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* actb = smem;
+    const int dummy_byte = G::L3_BYTES;
+    float* hs = reinterpret_cast<float*>(smem + G::L3_BYTES) + G::DUMMY_FLOATS;
+    __shared__ int dead;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    // blocks x + 8 (S j + s) are the S slices of group 8 j + x: one XCD, one L2 (see the one-board form)
+    const int sc = (bid >> 3) % S, grp = ((bid >> 3) / S) * 8 + (bid & 7);
+    if (grp >= a.tasks_p + a.tasks_v) return;           // the grid is padded to whole sets of 8 groups
+    const int net = grp >= a.tasks_p;
+    const bk_net_params& P = a.net[net];
+    const int b0 = (net ? a.off_v + (grp - a.tasks_p) * 3 : a.off_p + grp * 3);
+    const int nb = min(3, (net ? a.B_value : a.B_policy) - b0);
+    float* xb = a.coop_xchg + (size_t)grp * F::XCHG_FLOATS;
+    unsigned int* cnt = a.coop_sync + grp * BK_COOP_SYNC_STRIDE;
+
+    const int wm = wave / F::CT, wn = sc * F::CT + (wave - wm * F::CT);   // position group; this wave's cout tile (of 8)
+    f32x4 Wr[F::RING][1];
+    {
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int n = 0; n < F::RING - 1; ++n)
+            Wr[n][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr0, lane * 16, n * 8192, 0));
+    }
+    if (tid == 0) {
+        const bool poisoned = __hip_atomic_load(a.coop_sync + BK_COOP_POISON_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (poisoned) __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dead = poisoned;
+    }
+    stage_input<3, THREADS>(a, actb, b0, nb, tid);
+    __syncthreads();
+
+    const int kq = lane >> 4;
+    f32x4 acc[1][RT];
+    lds_cchar* ap3[RT];
+    unsigned valid = 0;
+    int xoff[RT];
+    const int store_c = RP3 + REC3 - kq * 16 + (16 * wn + 4 * kq) * 4;
+    f32x4 bv[1];
+    const int row_i = wm * RT * 16 + (lane & 15);
+    {
+        lds_cchar* ap0[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ap0[rt] = (lds_cchar*)actb + (g_rows<3>.a0[row_i + rt * 16] + kq * 16);
+        conv_layer<F, true>(actb, P.wfrag, acc, lane, wm, wn, ap0, Wr);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int e = g_rows<3>.a3v[row_i + rt * 16];
+        ap3[rt] = (lds_cchar*)actb + ((e & ~1) + kq * 16);
+        valid |= (unsigned)(e & 1) << rt;
+        const TileRow fr = tile_row<3>(wm, rt, lane & 15);
+        xoff[rt] = fr.valid ? (81 * fr.b + 9 * fr.y + fr.x) * 128 + 16 * wn + 4 * kq : -1;
+    }
+    load_bias<F>(bv, P.bias, wn, kq);
+    __syncthreads();                                    // everyone done reading the input planes
+    for (int i = tid; i < 38 * (REC3 / 16); i += THREADS) {   // the 38 halo records (see the 3-board form)
+        const int rec = i / (REC3 / 16), ch = i - rec * (REC3 / 16);
+        const int base = rec < 10 ? rec * REC3 : rec < 37 ? (rec - 9) * RP3 : G::NROWS3 * RP3;
+        *reinterpret_cast<f32x4*>(actb + base + ch * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, F::XCHG_FLOATS * 4, 0x00020000);
+    constexpr int SC1 = 16;
+    // own channels: LDS + exchange buffer; meet; the peers' channels into LDS.  After the last layer only slice 0 goes on.
+    auto exchange = [&](int L) -> bool {
+        const int par = (L & 1) * (243 * 128 * 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            typedef __attribute__((address_space(3))) char lds_char;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[0][rt][e] + bv[0][e], 0.f);
+            lds_char* wp = (valid >> rt) & 1 ? (lds_char*)(ap3[rt]) + store_c : (lds_char*)actb + dummy_byte;
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(wp) = v;
+            if (xoff[rt] >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xr, xoff[rt] * 4, par, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool last = L == 6;
+        if (a.coop_fault && L == 3 && grp == 0 && sc == 1) return false;   // test hook: a peer that never arrives
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(last && sc != 0) && !dead) {
+                const unsigned int target = (unsigned int)S * (L + 1);
+                int spins = 0;
+#pragma unroll 1
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > COOP_SPIN_LIMIT) {
+                        __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(a.coop_sync + BK_COOP_POISON_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        if (last && sc != 0) return false;              // uniform over the workgroup
+        __syncthreads();
+        // the peers' channels: chunk j = (point q, foreign 16-byte channel chunk cf), eight in flight per thread
+        constexpr int OWN = 32 / SC, FC = 32 - OWN, N = 243 * FC, PER = (N + THREADS - 1) / THREADS, BATCH = 8;
+#pragma unroll 1
+        for (int k0 = 0; k0 < PER; k0 += BATCH) {
+            f32x4 v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int j = tid + THREADS * (k0 + k);
+                if (j < N) {
+                    const int q = j / FC, cf = j - q * FC, c = cf < sc * OWN ? cf : cf + OWN;
+                    v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, q * 512 + c * 16, par, SC1));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int j = tid + THREADS * (k0 + k);
+                if (j < N) {
+                    const int q = j / FC, cf = j - q * FC, c = cf < sc * OWN ? cf : cf + OWN;
+                    const int b = q / 81, r = q - 81 * b, y = r / 9, x = r - 9 * y;
+                    *reinterpret_cast<f32x4*>(actb + G::addr3(b, y, x) + c * 16) = v[k];
+                }
+            }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    exchange(0);
+#pragma unroll 1
+    for (int L = 1; L < 7; ++L) {
+        conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, ap3, Wr);
+        load_bias<F>(bv, P.bias + L * 128, wn, kq);
+        __syncthreads();
+        if (!exchange(L)) return;
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (wave < nb) run_heads<G>(a, P, actb, hs + wave * 96, net, lane, wave, b0 + wave);
+}
+
+template <int SC>
+hipError_t launch_coop3(const bk_eval_args& a, hipStream_t stream) {
+    static bool attr_set_dev[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    auto kern = bk_leaf_eval_coop3_kernel<SC>;
+    if (!attr_set_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set_dev[dev] = true;
+    }
+    bk_eval_args args = a;
+    args.tasks_p = (a.B_policy - a.off_p + 2) / 3;
+    args.tasks_v = (a.B_value - a.off_v + 2) / 3;
+    const int groups = args.tasks_p + args.tasks_v;
+    if (groups == 0) return hipSuccess;
+    if (groups > BK_COOP3_MAX_GROUPS) return hipErrorInvalidValue;
+    const int grid = (groups + 7) / 8 * 8 * SC;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Coop3Tiles<SC>::THREADS), Geo<3>::LDS_BYTES, stream, args);
+    return hipGetLastError();
+}
+
 template <int NB, bool GATED>
 hipError_t launch_nb(const bk_eval_args& a, hipStream_t stream) {
     static bool attr_set_dev[64] = {false};  // the attribute is per device: one flag per device ordinal
@@ -1065,11 +1258,33 @@ int bk_coop_slices(int tasks, int n_cu) {
     return 0;
 }
 
+// three boards on 2 / 4 CUs for the requests between the whole-board forms' ranges; 0: use the ordinary forms.
+// Groups (three boards of one net) are dealt to the XCDs like the one-board form's tasks: ceil(groups / 8) x SC CUs of one XCD.
+int bk_coop3_form(int B_policy, int B_value, int n_cu) {
+    const int tasks = B_policy + B_value, groups = (B_policy + 2) / 3 + (B_value + 2) / 3;
+    if (tasks <= 0 || groups > BK_COOP3_MAX_GROUPS) return 0;
+    const int per_xcd = (groups + 7) / 8, cus = n_cu / 8;
+    if (const char* f = getenv("BK_COOP")) {
+        if (atoi(f) == 0) return 0;                     // BK_COOP=0: no cooperative launch of either kind
+    }
+    if (const char* f = getenv("BK_COOP3")) {
+        const int v = atoi(f);
+        if (v == 0) return 0;
+        if ((v == 2 || v == 4) && per_xcd * v <= cus) return v == 2 ? BK_COOP3_FORM_2 : BK_COOP3_FORM_4;
+    }
+    // measured (tools/coop_probe.py): see DESIGN 3
+    if (tasks > BK_COOP_MAX_TASKS && tasks <= BK_COOP3_FORM_4_MAX && per_xcd * 4 <= cus) return BK_COOP3_FORM_4;
+    if (tasks > n_cu && tasks <= BK_COOP3_FORM_2_MAX && per_xcd * 2 <= cus) return BK_COOP3_FORM_2;
+    return 0;
+}
+
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream) {
     // wave grids measured (us per call at 2 / 63 tasks): 4 slices: 2 row groups 111 / 116, 3: 138 / 145, 6: 118 / 128;
     // 8 slices: 6 row groups 86, 3: 84;  2 slices: 2 row groups 189 / 194, 3: 200 / 204.  Every wave arriving and polling
     // for itself (no workgroup barriers around the meeting point): 177 at 63 tasks -- four times the pollers on the counters
     switch (slices) {
+        case BK_COOP3_FORM_2: return launch_coop3<2>(a, stream);   // three boards on two CUs
+        case BK_COOP3_FORM_4: return launch_coop3<4>(a, stream);   // three boards on four CUs
         case 12: return launch_coop<4, 3, 2>(a, stream);  // 4 cout ranges x 3 point ranges: 4 waves x 1 tile
         case 6: return launch_coop<2, 3, 2>(a, stream);   // 2 x 3: 8 waves x 1 tile
         case 8: return launch_coop<8, 1, 6>(a, stream);

@@ -55,6 +55,8 @@ def test_plan_flops_counts_the_tile_tables(lib):
     assert q(1, 62, coop=1) == (63 * one, 2.0 * (66706944 + 62 * 66712192), 1) == q(1, 62, coop=0)     # 63 tasks: 4 CUs per board
     assert q(1, 70, coop=1)[0] == 71 * every and q(1, 70, coop=0)[0] == 71 * one                       # 71 tasks: 3 CUs per board
     assert one / every < 0.9
+    assert q(2, 150, coop=1)[0] == (1 + 50) * 435355648 and q(20, 300, coop=1)[0] == (7 + 100) * 435355648   # three boards on 4 / 2 CUs: the 3-board tile set per group
+    assert q(2, 150, coop=0)[0] == 152 * one
     assert q(0, 0) == (0.0, 0.0, 0) and lib.bk_plan_flops(-1, 0, 256, 0, None, None, None) == -1
     assert lib.bk_plan_flops(5, 5, 256, 0, None, None, None) == 0   # every out pointer may be NULL
 
@@ -182,12 +184,19 @@ def test_comm_library_symbols_and_cpu_errors():
 def test_launch_planner_choices(lib, monkeypatch):
     """bk_plan_query: the planner's decisions as a pure function -- CUs per board of the cooperative small-batch form by
     task count (what fits is ceil(tasks / 8) groups on the n_cu / 8 CUs of an XCD) and boards per workgroup otherwise."""
-    for v in ("BK_COOP", "BK_FORCE_NB"):
+    for v in ("BK_COOP", "BK_COOP3", "BK_FORCE_NB"):
         monkeypatch.delenv(v, raising=False)
     nb = ctypes.c_int(0)
     q = lambda npol, nval, prec=0, n_cu=256: lib.bk_plan_query(npol, nval, n_cu, prec, ctypes.byref(nb))  # noqa: E731
     assert [q(1, 1), q(1, 7), q(1, 8), q(1, 31), q(1, 32), q(1, 39), q(1, 40), q(1, 63), q(1, 64), q(1, 79), q(1, 80), q(0, 128),
-            q(1, 128), q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 2, 2, 0, 0]
+            q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 2, 2, 0]
+    # between the whole-board forms' ranges: three boards of one net on 4 CUs (code 104: 129..192 tasks, while the groups
+    # of three fit 8 to an XCD) and on 2 CUs (102: 257..384 tasks, 16 groups to an XCD)
+    assert [q(1, 128), q(2, 150), q(6, 186), q(1, 190), q(1, 191), q(8, 200), q(0, 256), q(1, 256), q(20, 300), q(30, 340), q(3, 381),
+            q(4, 380), q(14, 370), q(1, 384)] == [104, 104, 104, 0, 0, 0, 0, 102, 102, 102, 102, 0, 0, 0]
+    monkeypatch.setenv("BK_COOP3", "0")
+    assert q(1, 128) == 0 and q(1, 256) == 0
+    monkeypatch.delenv("BK_COOP3")
     assert q(1, 62, 1) == 0                      # f16x2 engines keep the one-CU form
     assert q(1, 15, 0, 64) == 4 and q(1, 16, 0, 64) == 2 and q(1, 32, 0, 64) == 0   # a 64-CU device: 8 CUs per XCD
     assert q(4096, 4096) == 0 and nb.value == 3
@@ -195,4 +204,4 @@ def test_launch_planner_choices(lib, monkeypatch):
     assert q(300, 300) == 0 and nb.value in (2, 3)
     assert lib.bk_plan_query(-1, 0, 256, 0, None) == -1 and lib.bk_plan_query(1, 1, 0, 0, None) == -1
     monkeypatch.setenv("BK_COOP", "0")
-    assert q(1, 62) == 0
+    assert q(1, 62) == 0 and q(1, 128) == 0 and q(1, 256) == 0

@@ -513,6 +513,48 @@ def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
     other.close()
 
 
+def test_three_boards_on_two_or_four_cus_give_the_same_bits(monkeypatch):
+    """Requests between the whole-board forms' ranges (129..192 and 257..384 tasks) run as groups of three boards of one net
+    shared by 4 resp. 2 CUs (bk_leaf_eval_coop3_kernel: output channels split, the 3-board tile set, the cooperative
+    exchange): every output bit-identical to the whole-board forms (BK_COOP3=0), partial groups, policy rows and both forced
+    forms included; a deserting peer ends in the usual fallback with the usual bits."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x = make_batch(384, seed_base=77_000, dtype=np.uint8)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = LeafEngine(pw, vw, max_batch=512)
+    shapes = ((128, 1), (131, 0), (150, 2), (170, 10), (186, 6), (256, 1), (257, 0), (299, 31), (340, 30), (378, 6))
+    monkeypatch.setenv("BK_COOP3", "0")
+    ref = [eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol) for B, npol in shapes]
+    assert eng.stats()["coop_launches"] == 0
+    for mode in (None, "2", "4"):
+        if mode is None:
+            monkeypatch.delenv("BK_COOP3")
+        else:
+            monkeypatch.setenv("BK_COOP3", mode)
+        c0 = eng.stats()["coop_launches"]
+        for (B, npol), want in zip(shapes, ref):
+            if mode == "4" and B + npol > 192:
+                continue
+            got = eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol)
+            for k in want:
+                assert np.array_equal(want[k], got[k]), (mode, B, npol, k)
+        assert eng.stats()["coop_launches"] - c0 == (10 if mode != "4" else 5), mode
+    assert eng.stats()["coop_fallbacks"] == 0
+    monkeypatch.delenv("BK_COOP3")
+    c0 = eng.stats()["coop_launches"]
+    monkeypatch.setenv("BK_COOP_FAULT", "1")
+    bad = [eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol) for B, npol in ((150, 2), (340, 30))]
+    monkeypatch.delenv("BK_COOP_FAULT")
+    st = eng.stats()
+    assert st["coop_fallbacks"] == 2 and st["coop_launches"] - c0 == 2
+    good = eng.eval(x[:340], logits=True, probs=True, value=True, n_policy=30)
+    assert eng.stats()["coop_fallbacks"] == 2
+    for k in ref[2]:
+        assert np.array_equal(ref[2][k], bad[0][k]) and np.array_equal(ref[8][k], bad[1][k]) and np.array_equal(ref[8][k], good[k]), k
+    eng.close()
+
+
 def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
     """BK_COOP_FAULT makes one slice of one board leave before a meeting point: its peers give up after the bounded
     wait and raise the flag that travels with the outputs, bk_wait redoes the request with one CU per board
