@@ -1094,7 +1094,7 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
         if (last && sc != 0) return false;              // uniform over the workgroup
         __syncthreads();
         // the peers' channels: chunk j = (point q, foreign 16-byte channel chunk cf), eight in flight per thread
-        constexpr int OWN = 32 / SC, FC = 32 - OWN, N = 243 * FC, PER = (N + THREADS - 1) / THREADS, BATCH = 8;
+        constexpr int OWN = 32 / SC, FC = 32 - OWN, N = 243 * FC, PER = (N + THREADS - 1) / THREADS, BATCH = SC == 4 ? 12 : 8;
 #pragma unroll 1
         for (int k0 = 0; k0 < PER; k0 += BATCH) {
             f32x4 v[BATCH];
