@@ -22,7 +22,8 @@
 // HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2 resident).  BatchNorm (eval
 // mode) is folded into the weights on the host in fp64.
 // Batches of at most 128 (net, board) tasks take the cooperative form further down instead: 2 .. 12 workgroups on as
-// many CUs share one board, each computing a slice of every layer and exchanging slices through L2 (same bits).
+// many CUs share one board, each computing a slice of every layer and exchanging slices through L2 (same bits); requests
+// between the whole-board forms' ranges (129..192 and 257..384 tasks) run as groups of THREE boards shared by 4 resp. 2 CUs.
 //   * every conv dot product is summed in TWO fp32 chains (the halves of the kernel window), the heads in four: as close to
 //     the float64 evaluation of the network as the reference's own fp32 is (conv_layer below; tools/emu/kernel_emu.c
 //     reproduces the order on the CPU bit for bit).

@@ -212,7 +212,8 @@ int bk_engine_max_batch(bk_engine *e);
 /*
  * Launch planner, as a pure function (no engine, no GPU): how a request of n_policy PolicyNet rows + n_value ValueNet
  * rows would be launched on a device with n_cu compute units at `precision`.  Returns the CUs per board of the
- * cooperative small-batch form (12/8/6/4/3/2; ticket path, fp32 only), or 0 when the ordinary form runs;
+ * cooperative small-batch form (12/8/6/4/3/2; ticket path, fp32 only), 104 / 102 for groups of three boards shared by 4 / 2
+ * CUs (requests of 129..192 / 257..384 tasks), or 0 when the ordinary form runs;
  * *boards_per_workgroup (may be NULL) receives the ordinary form's workgroup size (1..3) for a single launch.
  */
 int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int *boards_per_workgroup);
