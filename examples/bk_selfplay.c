@@ -92,6 +92,8 @@ int main(int argc, char **argv) {
                 if (prm.eager_top <= 2) {          /* ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups */
                     int rounds = (2 * k + 128) / 256;
                     bk_pool_set_task_cap(s[i].pool, 256 * (rounds < 1 ? 1 : rounds) - 4);
+                } else if (3 * k > 128 && 3 * k <= 192) {
+                    bk_pool_set_task_cap(s[i].pool, 188);   /* within the range of the three-boards-on-four-CUs launch */
                 } else {
                     int rounds = (3 * k + 384) / 768;
                     bk_pool_set_task_cap(s[i].pool, 768 * (rounds < 1 ? 1 : rounds) - 4);
