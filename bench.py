@@ -29,7 +29,8 @@ The headline (`value`, `dtype`, `roofline`) is the EXACT-fp32 kernel -- the refe
                 ranks + the end-of-generation all-reduce), per precision, with a CPU baseline at N=1.
   small_batch_latency  secondary: kernel time of the batches a single-tree genmove issues (configs[2]/[4]: 1 policy row +
                 ~60 value rows) and of a single position (configs[0]), one CU per board against the cooperative
-                launch (4 resp. 12 CUs per board; bit-identical outputs)
+                launch (4 resp. 12 CUs per board; bit-identical outputs); and of requests between the whole-board forms'
+                ranges (150 / 300 boards: three boards shared by 4 / 2 CUs)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -879,6 +880,13 @@ def main():
             coop = kernel_us(B)
             small[f"B{B}"] = {"one_cu_per_board_us": one_cu[0], "cooperative_us": coop[0], "cooperative_launches": coop[1],
                               "fallbacks": coop[2]}
+        # requests between the whole-board forms' ranges: groups of three boards shared by 4 / 2 CUs (bk_leaf_eval_coop3_kernel)
+        for B, key in ((150, "three_boards_on_4_cus_us"), (300, "three_boards_on_2_cus_us")):
+            os.environ["BK_COOP"] = "0"
+            whole = kernel_us(B)
+            os.environ.pop("BK_COOP")
+            coop = kernel_us(B)
+            small[f"B{B}"] = {"whole_board_workgroups_us": whole[0], key: coop[0], "cooperative_launches": coop[1], "fallbacks": coop[2]}
         if saved is not None:
             os.environ["BK_COOP"] = saved
 
