@@ -729,6 +729,9 @@ struct Game {
                 }
                 case S_IDLE:
                     if (remaining > 0) { state = S_SEARCH; break; }
+                    // rows asked for by the last rollout's expansion (branch_num: it happens once the priors are in, right
+                    // before the search goes idle) still go out: nothing may be left waiting when the caller moves on
+                    if (has_request()) return true;
                     return false;
                 case S_DONE:
                     return false;

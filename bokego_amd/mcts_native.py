@@ -318,8 +318,11 @@ class NativeMCTS:
         if r._terminal:
             return r
         mv = self._lib.bk_pool_choose(self._pool._h, 0)
-        if mv == go._NO_MOVE:      # no legal move at all: pass (the Python tree samples, ending in a pass)
-            self.play(go.PASS)
+        if mv == go._NO_MOVE:
+            # the root has no children -- no legal move at all, or (branch_num) none among the policy's top k: the reference's
+            # max() over an empty set raises here; like the Python tree, sample a move from the policy (a pass as the last resort)
+            child = self._sample_child(r)
+            self.play(go.PASS if child.last_move is None else child.last_move)
         self._pump()
         return self.root
 

@@ -348,3 +348,51 @@ def test_branch_num_on_the_native_tree_is_the_python_trees_search(k):
         assert a.last_move == b.last_move
     assert max(len(nat.children[n]) for n in nat.children) <= k
     assert nat._pool.info(0)["root_N"] == py.N[py.root]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_parameters_and_operations_match_the_python_tree(seed):
+    """Fuzz: random search parameters (expand_thresh, branch_num; on the native side evaluation ahead, request sizes, children
+    per expansion, collect cap) and random sequences of rollouts, choose() and outside moves -- after every step the native
+    tree's root, its children's N and V and the win rate equal the Python tree's.  (Found in round 4: rows asked for by an
+    expansion that happens right before the search goes idle (branch_num) were left waiting, and choose() on a root without
+    children (none of the policy's top k legal) passed where the Python tree samples a move.)"""
+    import random
+    from bokego_amd import selfplay
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    rng = random.Random(seed)
+    for case in range(25):
+        kw = dict(expand_thresh=rng.choice([1, 2, 3, 5, 8, 13, 30]))
+        bn = rng.choice([None, None, 3, 8, 20])
+        if bn:
+            kw["branch_num"] = bn
+        nkw = dict(kw, speculate=rng.choice([0, 2, 5, 20]), speculate_rows=rng.choice([82, 100, 256]), request_tasks=rng.choice([0, 16, 64]),
+                   eager_top=rng.choice([0, 0, 2, 4]), cap=rng.choice([82, 128, 1024]))
+        if nkw["request_tasks"]:
+            nkw["request_steps"] = (nkw["request_tasks"], nkw["request_tasks"] + 16, nkw["request_tasks"] * 2)
+        py = MCTS(Go_MCTS(), _Wrap(pol), _Wrap(val, True), **kw)
+        nat = NativeMCTS(Position(), evaluator=selfplay.CallableEvaluator(pol, val), **nkw)
+        for step in range(rng.randint(3, 12)):
+            op = rng.random()
+            if op < 0.6:
+                n = rng.randint(1, 100)
+                py.rollout(n); nat.rollout(n)
+            elif op < 0.85:
+                torch.manual_seed(step); a = py.choose()
+                torch.manual_seed(step); b = nat.choose()
+                assert a.last_move == b.last_move, (case, kw, nkw, step)
+            else:
+                legal = list(py.root.get_legal_moves())
+                if not legal:
+                    break
+                mv = rng.choice(legal)
+                py.set_root(py.root.make_move(mv)); nat.set_root(nat.root.make_move(mv))
+            assert nat.root.key() == py.root.key(), (case, kw, nkw, step)
+            if py.root._terminal:
+                break
+            want = {c.mv: (py.N[c], py.V[c]) for c in py.children[py.root]} if py.root in py.children else {}
+            assert nat.child_stats() == want, (case, kw, nkw, step)
+            assert abs(nat.winrate() - py.winrate()) < 1e-12
+        nat.close()
