@@ -76,10 +76,10 @@ class RefMCTS:
 
     def _probs(self, g):
         f = g.features_u8().astype(np.float32)[None]
-        lg = np.asarray(self.policy_fn(f), dtype=np.float32)[0]
-        e = np.exp(lg - lg.max(), dtype=np.float32)
-        p = e / e.sum(dtype=np.float32)
-        p = p / p.sum(dtype=np.float32)               # Categorical re-normalises (nnet.py:274)
+        import torch
+        lg = torch.from_numpy(np.asarray(self.policy_fn(f), dtype=np.float32).reshape(1, 81))
+        p = torch.softmax(lg, dim=1)                  # SOFT (nnet.py:16,273)
+        p = (p / p.sum(-1, keepdim=True))[0]          # Categorical re-normalises (nnet.py:274)
         self.n_policy_calls += 1
         return [float(x) for x in p]
 
