@@ -190,8 +190,9 @@ class _GTPProtocol:
     def _install_root(self, node, keep_komi=True):
         self.set_root(node)
         if not keep_komi:
-            self._set_komi(5.5)        # the tree may hand back an interned node that still carries the old value
-            self._komi = None
+            # (and it stays in force: the Python tree hands back interned nodes -- a position reached again after the
+            # clear_board -- that still carry the komi of before; found by a fuzzed session, round 4)
+            self._set_komi(5.5)
         elif self._komi is not None:
             self._set_komi(self._komi)
 

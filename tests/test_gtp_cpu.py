@@ -176,3 +176,43 @@ def test_live_stream_ponders_and_streams_analysis(nets, native):
     lines = body.split("\n")
     assert lines[0] == "= " and sum(ln.startswith("info move ") for ln in lines) >= 2, body
     assert body.endswith("\n\n") and text.rstrip().endswith("=")          # analyze's terminator; quit's "= "
+
+
+def test_fuzzed_sessions_give_the_same_replies_on_both_trees():
+    """Random GTP sessions (play, pass, genmove, reg_genmove, undo, clear_board, komi, final_score, handicap, showboard) on the
+    Python tree and on the native tree: every reply equal.  And the case such a session found in round 4: after `clear_board`
+    the komi is 5.5 again (gtp.py:147-149) also on a position the Python tree had interned under the old komi."""
+    import random
+    import numpy as np
+    from bokego_amd.gtp import NativeGTP
+    from bokego_amd.mcts_native import Position
+    from test_selfplay_cpu import FakeNets, _Wrap
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+
+    def pair(**kw):
+        a = GTP(Go_MCTS(), _Wrap(pol), _Wrap(val, True), **kw)
+        b = NativeGTP(Position(), _Wrap(pol), _Wrap(val, True), **kw)
+        a.running = b.running = True
+        return a, b
+
+    for g in pair(no_sim=True, time_lim=None, n_rollouts=5, expand_thresh=20):
+        for cmd in ("play b pass", "komi 0.5", "final_score", "clear_board", "play b pass"):
+            g.send(cmd)
+        assert g.send("final_score") == "= W+5.5\n\n"
+    rng = random.Random(4)
+    cols = "ABCDEFGHJ"
+    for _ in range(40):
+        a, b = pair(no_sim=True, time_lim=None, n_rollouts=rng.choice([5, 20, 60]), expand_thresh=rng.choice([2, 5, 20]))
+        log = []
+        for step in range(rng.randint(4, 25)):
+            r = rng.random()
+            cmd = (f"play {rng.choice('bw')} {rng.choice(cols)}{rng.randint(1, 9)}" if r < 0.35 else f"play {rng.choice('bw')} pass" if r < 0.45 else
+                   f"genmove {rng.choice('bw')}" if r < 0.7 else "undo" if r < 0.78 else "clear_board" if r < 0.82 else
+                   f"komi {rng.choice(['5.5', '6.5', '0.5'])}" if r < 0.86 else "final_score" if r < 0.9 else
+                   f"set_fixed_handicap {rng.randint(2, 9)}" if r < 0.93 else "showboard" if r < 0.96 else f"reg_genmove {rng.choice('bw')}")
+            torch.manual_seed(step); ra = a.send(cmd)
+            torch.manual_seed(step); rb = b.send(cmd)
+            log.append((cmd, ra))
+            assert ra == rb, (log[-6:], rb)
