@@ -132,6 +132,57 @@ def test_config3_on_native_tree(sds):
     print(f"\nconfig3 native: {dt*1e3:.1f} ms/move, mean batch {ev.positions/ev.batches:.1f}")
 
 
+def _replay_whole_game(tree, t, native):
+    """rollout(1600) + choose() for every move of the recorded game; returns seconds per move"""
+    t0 = time.time()
+    for ply, ref in enumerate(t["moves"]):
+        tree.rollout(t["rollouts"])
+        if native:
+            kids = {m: n for m, (n, _) in tree.child_stats().items()}
+            root_n = tree.N[tree.root]
+        else:
+            kids = {c.mv: tree.N[c] for c in tree.children[tree.root]}
+            root_n = tree.N[tree.root]
+        assert kids == {int(k): v for k, v in ref["child_N"].items()}, ply
+        assert root_n == ref["root_N"], ply
+        assert abs(tree.winrate() - ref["root_winrate"]) < 1e-4, ply
+        best = tree.choose()
+        assert best.last_move == ref["move"], (ply, best.last_move, ref["alpha"])
+    assert tree.root.board == t["final_board"] and tree.root.turn == t["final_turn"]
+    assert tree.root._terminal and tree.choose().key() == tree.root.key()      # turn > MAX_TURNS: mcts.py:116-118,362-364
+    return (time.time() - t0) / len(t["moves"])
+
+
+def test_config3_whole_game_matches_reference_on_both_trees(sds):
+    """VERDICT r4 next #1b: the regime in which ms/move is quoted -- a WHOLE game (81 moves, until turn > MAX_TURNS) of
+    1600-rollout searches with the tree re-used from move to move, recorded from the reference itself
+    (tools/gen_golden.py --only-game -> tests/golden/mcts_trace_game.json; 3,687 value + 845 policy evaluations there).
+    Every move, every root-child visit count, the root's visit count and winrate before each move, and the final board are
+    the reference's, on the Python tree and on the native tree (its default: evaluation ahead of expansion, requests held
+    to the cooperative launch's size steps)."""
+    from bokego_amd import nnet
+    from bokego_amd.mcts import MCTS, Go_MCTS
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace_game.json")))["r1600_game"]
+    assert len(t["moves"]) == 81 and t["rollouts"] == 1600
+    pi, val = nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1])
+    torch.manual_seed(0)
+    ms_py = _replay_whole_game(MCTS(Go_MCTS(), pi, val, no_sim=True), t, native=False) * 1e3
+    nat = NativeMCTS(Position(), pi, val)
+    ms_nat = _replay_whole_game(nat, t, native=True) * 1e3
+    gi = nat._pool.info(0)
+    print(f"\nconfig3 whole game (81 moves): Python tree {ms_py:.1f} ms/move, native tree {ms_nat:.2f} ms/move "
+          f"({gi['n_requests'] / 81:.1f} requests, {gi['n_value_evals'] / 81:.0f} value rows per move); "
+          f"reference: {t['n_value_evals']} value / {t['n_policy_evals']} policy evaluations, ~0.9 s/move")
+    out = os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r05_cfg2_whole_game.json"), "w") as f:
+            json.dump({"moves": 81, "rollouts": 1600, "python_tree_ms_per_move": ms_py, "native_tree_ms_per_move": ms_nat,
+                       "native_requests_per_move": gi["n_requests"] / 81, "native_value_rows_per_move": gi["n_value_evals"] / 81,
+                       "identical_to_reference": True}, f)
+
+
 @pytest.mark.parametrize("precision,kw", [("f16x2", {}), ("f32", {"speculate": 60, "speculate_rows": 256, "request_tasks": 0}), ("f32", {})])
 def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
     """search_params.speculate (the default of NativeMCTS on an f16x2 engine; forced here for fp32 in its whole-candidate

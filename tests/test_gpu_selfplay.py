@@ -79,29 +79,57 @@ def test_config4_does_not_depend_on_what_is_evaluated_when(engine, generation):
             assert tot["value_evals"] > 4 * total["value_evals"]
 
 
-def test_config4_games_start_like_the_cpu_oracle_run(generation, sds):
-    """(iii) anchored to the oracle, not to the HIP path itself: the native pool driven by the CPU oracle nets
-    (CallableEvaluator) plays the first plies of sampled games of the SAME generation (same seeds, 400 rollouts,
-    Dirichlet noise and visit sampling included); moves and root visit counts must equal the GPU run's."""
+ORACLE_GIDS = list(range(5, 512, 16))          # 32 of the 512 games, spread over the shards of every world size
+
+
+def test_config4_whole_games_equal_the_cpu_oracle_run(generation, sds):
+    """(iii) anchored to the oracle, not to the HIP path itself (VERDICT r4 next #1a): the native pool driven by the CPU
+    oracle nets (oracle/nnet_ref.c through CallableEvaluator) plays 32 of the 512 games of the SAME generation TO THE END
+    -- same seeds, 400 rollouts/move, Dirichlet noise and visit sampling included -- and every move and every root-child
+    visit count of every ply must equal the GPU run's.  The two sides' network outputs differ by ~3e-5, so a PUCT near-tie
+    may resolve the other way round: at least 30 of the 32 games must be identical, and where one is not, its first
+    divergent ply must be a visit tie within 1 (one rollout gone to a sibling).  The figures go to
+    gpurun_out/r05_cfg3_oracle_depth.json (committed under profiles/)."""
+    import time
     from oracle.oracle import OraclePolicy, OracleValue, set_threads
     set_threads(min(16, len(os.sched_getaffinity(0))))
     P, V = OraclePolicy(sds[0]), OracleValue(sds[1])
     local, _ = generation
-    plies = 10
-    gids = [0, 77, 200, 341, 511]
     prm = selfplay.search_params(rollouts=400, expand_thresh=100, noise_weight=0.25, sample_plies=8,
-                                 max_turns=80, prune=1, record_visits=1)     # exactly self_play()'s parameters
-    pool = selfplay.GamePool([20260 + g for g in gids], prm, cap=8192)
+                                 max_turns=80, prune=1, record_visits=1, eager_top=2)     # self_play()'s parameters
+    pool = selfplay.GamePool([20260 + g for g in ORACLE_GIDS], prm, cap=8192)
     ev = selfplay.CallableEvaluator(P, V)
-    while min(pool.info(i)["n_moves"] for i in range(len(gids))) < plies:    # the games advance in lock-step
-        feats, npol = pool.collect()
-        assert len(feats) > 0
-        pool.deliver(*ev(feats, npol))
-    for i, g in enumerate(gids):
-        assert pool.moves(i)[:plies] == local["games"][g]["moves"][:plies], g
-        for ply in range(plies):
-            assert pool.visits(i, ply) == local["visits"][g][ply], (g, ply)
+    t0 = time.perf_counter()
+    selfplay.run_pools([pool], ev)
+    secs = time.perf_counter() - t0
+    identical, plies, diverged = 0, 0, []
+    for i, g in enumerate(ORACLE_GIDS):
+        want_m, want_v = local["games"][g]["moves"], local["visits"][g]
+        got_m = pool.moves(i)
+        got_v = [pool.visits(i, ply) for ply in range(len(got_m))]
+        first = next((k for k in range(max(len(got_m), len(want_m)))
+                      if k >= len(got_m) or k >= len(want_m) or got_m[k] != want_m[k] or got_v[k] != want_v[k]), None)
+        if first is None:
+            identical += 1
+            plies += len(got_m)
+            assert pool.info(i)["score"] == local["games"][g]["score"]
+            continue
+        plies += first
+        a, b = (got_v[first] if first < len(got_v) else {}), (want_v[first] if first < len(want_v) else {})
+        dn = {m: a.get(m, 0) - b.get(m, 0) for m in set(a) | set(b) if a.get(m, 0) != b.get(m, 0)}
+        diverged.append({"gid": g, "ply": first, "delta_N": {str(k): v for k, v in dn.items()},
+                         "moves": [got_m[first] if first < len(got_m) else None, want_m[first] if first < len(want_m) else None]})
+    rec = {"games": len(ORACLE_GIDS), "identical_games": identical, "oracle_anchored_plies": plies, "diverged": diverged,
+           "oracle_seconds": secs, "oracle_positions": ev.positions, "oracle_threads": min(16, len(os.sched_getaffinity(0)))}
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r05_cfg3_oracle_depth.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("\ncfg[3] oracle depth:", {k: v for k, v in rec.items() if k != "diverged"}, diverged)
     pool.close()
+    assert identical >= 30 and plies >= 2000, rec
+    for d in diverged:
+        assert d["delta_N"] and max(abs(v) for v in d["delta_N"].values()) <= 1 and len(d["delta_N"]) <= 2, d
 
 
 def test_config4_f16x2_plays_the_same_generation(engine, generation):

@@ -396,3 +396,24 @@ def test_random_parameters_and_operations_match_the_python_tree(seed):
             assert nat.child_stats() == want, (case, kw, nkw, step)
             assert abs(nat.winrate() - py.winrate()) < 1e-12
         nat.close()
+
+
+def test_whole_reference_game_on_the_oracle_nets():
+    """tests/golden/mcts_trace_game.json: ONE whole game (81 moves, until turn > MAX_TURNS) of 1600-rollout searches recorded
+    from the reference's own MCTS (tools/gen_golden.py --only-game).  The native tree fed by the CPU oracle nets
+    (oracle/nnet_ref.c) reproduces every move, every root-child visit count, the root's winrate before each move and the
+    final board -- evaluating an expansion's four best-prior children only (eager_top), which is what keeps this a
+    half-minute test (6 k positions instead of 60 k) and is the same search by construction."""
+    from bokego_amd import selfplay
+    from oracle.oracle import OraclePolicy, OracleValue
+    P = OraclePolicy(load_bkw(os.path.join(GOLDEN, "policy_19.bkw")))
+    V = OracleValue(load_bkw(os.path.join(GOLDEN, "value_synth.bkw")))
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace_game.json")))["r1600_game"]
+    assert len(t["moves"]) == 81
+    tree = NativeMCTS(Position(), evaluator=selfplay.CallableEvaluator(P, V), eager_top=4)
+    for ply, ref in enumerate(t["moves"]):
+        tree.rollout(t["rollouts"])
+        assert {m: n for m, (n, _) in tree.child_stats().items()} == {int(k): v for k, v in ref["child_N"].items()}, ply
+        assert tree.N[tree.root] == ref["root_N"] and abs(tree.winrate() - ref["root_winrate"]) < 1e-4, ply
+        assert tree.choose().last_move == ref["move"], ply
+    assert tree.root.board == t["final_board"] and tree.root._terminal

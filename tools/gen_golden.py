@@ -182,14 +182,49 @@ def gtp_transcript(pi, v):
     return out
 
 
+def whole_game_trace(pi, v, n_roll=1600, max_moves=100):
+    """One WHOLE game of the reference's search against itself: n_roll rollouts before every move, choose() until the root
+    is terminal (turn > MAX_TURNS, mcts.py:362-364) or has no child -- the regime in which ms/move over 80-move games is
+    quoted.  The tree and its statistics are re-used across moves as GTP.genmove does (mcts.py:110-131)."""
+    mcts.MCTS._val_cache.clear(); mcts.MCTS._dist_cache.clear(); mcts.MCTS._fts_cache.clear()
+    torch.manual_seed(0)
+    tree = mcts.MCTS(mcts.Go_MCTS(), pi, v, no_sim=True)
+    moves = []
+    t0 = time.time()
+    while len(moves) < max_moves:
+        root = tree.root
+        if root._terminal or not tree.children.get(root):
+            break
+        tree.rollout(n_roll)
+        kids = {int(c.last_move): int(tree.N[c]) for c in tree.children[root]}
+        rootN = int(tree.N[root]); wr = float(tree.winrate())
+        best = tree.choose()
+        moves.append({"move": int(best.last_move), "alpha": go.unsquash(best.last_move), "root_N": rootN,
+                      "root_winrate": wr, "child_N": kids, "best_V": float(tree.V[best])})
+        print(len(moves), moves[-1]["alpha"], rootN, max(kids.values()), f"{time.time() - t0:.0f}s", flush=True)
+    out = {"r%d_game" % n_roll: {"rollouts": n_roll, "kwargs": {}, "moves": moves,
+                                  "final_board": tree.root.board, "final_turn": int(tree.root.turn),
+                                  "n_value_evals": len(mcts.MCTS._val_cache),
+                                  "n_policy_evals": len(mcts.MCTS._dist_cache)}}
+    with open(os.path.join(OUT, "mcts_trace_game.json"), "w") as f:
+        json.dump(out, f)
+    print("whole game:", len(moves), "moves in", f"{time.time() - t0:.0f}s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-gtp", action="store_true")
     ap.add_argument("--skip-mcts", action="store_true")
+    ap.add_argument("--only-game", action="store_true",
+                    help="only the whole-game 1600-rollout trace (tests/golden/mcts_trace_game.json)")
+    ap.add_argument("--game-rollouts", type=int, default=1600)
     ap.add_argument("--playouts", type=int, default=256)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     pi, v = build_nets()
+    if args.only_game:
+        whole_game_trace(pi, v, args.game_rollouts)
+        return
     if args.only_gtp:
         with open(os.path.join(OUT, "gtp_transcript.json"), "w") as f:
             json.dump({"n_rollouts": 200, "session": gtp_transcript(pi, v)}, f, indent=0)
