@@ -567,7 +567,8 @@ def fold_counter_rows(rows, tot):
     """One rocprofv3 --pmc pass (rows of *_counter_collection.csv, already filtered to the leaf kernel) -> per-STEP counter
     values added into `tot`: a step is every launch the timed call makes (3-board rounds + 2-board tail = two kernels, or two
     grids of one); launches that do not occur in every step are left out.  Per launch kind the mean over its dispatches, summed
-    over the kinds; "_ns" accumulates the kernels' durations alongside GRBM_GUI_ACTIVE (for the clock).  False: nothing usable."""
+    over the kinds; "_ns" accumulates the kernels' durations alongside GRBM_GUI_ACTIVE (for the clock), "_ns_<counter>" the same
+    for every counter's own pass (the child's kernel time under that pass).  False: nothing usable."""
     kinds = {}
     for x in rows:
         kinds.setdefault((x["Kernel_Name"], x["Grid_Size"]), []).append(x)
@@ -582,6 +583,7 @@ def fold_counter_rows(rows, tot):
             per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
         for c, vals in per.items():
             tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
+            tot["_ns_" + c] = tot.get("_ns_" + c, 0.0) + sum(b for _, b in vals) / len(vals)   # the kernels' durations in THIS pass
             if c == "GRBM_GUI_ACTIVE":
                 tot["_ns"] = tot.get("_ns", 0.0) + sum(b for _, b in vals) / len(vals)
     return True
@@ -629,8 +631,13 @@ def live_counters(batch, precision, timeout_s=150, device=0):
         out["hbm_traffic_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
     if tot.get("GRBM_GUI_ACTIVE") and tot.get("_ns"):
         out["effective_clock_ghz"] = tot["GRBM_GUI_ACTIVE"] / 8 / tot["_ns"]
+        # the CHILD's own kernel time per step (profiler timestamps), in the clock pass and in the MFMA-counter pass: the
+        # factors below multiply to the fraction AT THIS TIME, not at the timed loop's (which runs at its own clock)
+        out["pmc_kernel_ms"] = tot["_ns"] / 1e6
         if tot.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             out["mfma_busy"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (tot["GRBM_GUI_ACTIVE"] / 8)
+            if tot.get("_ns_SQ_VALU_MFMA_BUSY_CYCLES"):
+                out["pmc_kernel_ms_mfma_pass"] = tot["_ns_SQ_VALU_MFMA_BUSY_CYCLES"] / 1e6
     if tot.get("SQ_INSTS_VALU_MFMA_MOPS_F32"):
         out["executed_mfma_flop_per_launch"] = tot["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
     return out
@@ -683,6 +690,12 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
                         "-- an upper bound on HBM bytes (both nets' workgroups read the planes; each XCD's L2 re-fetches its net's weights)")
     if live and live.get("executed_mfma_flop_per_launch"):
         r["pmc_executed_mfma_flop_per_launch"] = live["executed_mfma_flop_per_launch"]
+    if live and live.get("pmc_kernel_ms"):
+        # the counter child and the timed loop do not run at the same clock, so the line carries the
+        # child's own kernel time and the fraction AT that time; mfma_busy x clock / 2.4 GHz / executed_ratio reproduces it
+        r["pmc_kernel_ms"] = live["pmc_kernel_ms"]
+        r["pmc_kernel_ms_mfma_pass"] = live.get("pmc_kernel_ms_mfma_pass")
+        r["frac_at_pmc_kernel_ms"] = batch * FLOP_PER_LEAF / (live["pmc_kernel_ms"] * 1e-3) / 1e12 / peak
     if f16:
         # nominal: 3 half-precision MFMAs per algorithmic (fp32-equivalent) MAC, before padding and skipped zero-halo taps
         # (executed_mfma_tflops below is the counted figure for 3-board workgroups)
@@ -696,6 +709,9 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
             r["executed_mfma_flop_per_launch"] = ex["executed_mfma_flop_per_launch"]
             r["executed_mfma_tflops"] = ex["executed_mfma_flop_per_launch"] / (kern_ms * 1e-3) / 1e12
             r["executed_frac_of_peak"] = r["executed_mfma_tflops"] / peak
+            if live and live.get("mfma_busy") and live.get("effective_clock_ghz"):
+                r["frac_from_pmc_factors"] = live["mfma_busy"] * live["effective_clock_ghz"] / 2.4 / ex["ratio"]
+                r["frac_from_pmc_factors_formula"] = "mfma_busy x effective_clock_ghz / 2.4 / executed_mfma_flop_per_algorithmic_flop = frac_at_pmc_kernel_ms"
             if pmc.get("executed_mfma_flop_per_workgroup"):     # the counters' view of the same number, per 3-board workgroup
                 r["pmc_executed_mfma_flop_per_workgroup"] = pmc["executed_mfma_flop_per_workgroup"]
                 r["tile_table_mfma_flop_per_3_board_workgroup"] = ex["executed_mfma_flop_per_3_board_workgroup"]
@@ -872,23 +888,18 @@ def main():
             return (1e3 * (s1["kernel_ms_sum"] - s0["kernel_ms_sum"]) / (s1["kernel_ms_count"] - s0["kernel_ms_count"]),
                     s1["coop_launches"] - s0["coop_launches"], s1["coop_fallbacks"] - s0["coop_fallbacks"])
         small = {"what": "kernel time (HIP events) of one host-path evaluation of B boards + 1 policy row, us"}
-        saved = os.environ.get("BK_COOP")
         for B in (1, 62):
-            os.environ["BK_COOP"] = "0"
-            one_cu = kernel_us(B)
-            os.environ.pop("BK_COOP")
+            with eng.options(coop=0):
+                one_cu = kernel_us(B)
             coop = kernel_us(B)
             small[f"B{B}"] = {"one_cu_per_board_us": one_cu[0], "cooperative_us": coop[0], "cooperative_launches": coop[1],
                               "fallbacks": coop[2]}
         # requests between the whole-board forms' ranges: groups of three boards shared by 4 / 2 CUs (bk_leaf_eval_coop3_kernel)
         for B, key in ((150, "three_boards_on_4_cus_us"), (300, "three_boards_on_2_cus_us")):
-            os.environ["BK_COOP"] = "0"
-            whole = kernel_us(B)
-            os.environ.pop("BK_COOP")
+            with eng.options(coop=0):
+                whole = kernel_us(B)
             coop = kernel_us(B)
             small[f"B{B}"] = {"whole_board_workgroups_us": whole[0], key: coop[0], "cooperative_launches": coop[1], "fallbacks": coop[2]}
-        if saved is not None:
-            os.environ["BK_COOP"] = saved
 
     # Secondary measurement (outside the timed region above): BASELINE configs[3] -- 512 self-play games,
     # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
@@ -903,25 +914,61 @@ def main():
             threads = max(1, share - 4 if share > 8 else share - 1)      # as launch_plan: room for the HIP runtime's thread
         threads = max(1, min(12, threads, (args.selfplay_games // world) // 16 or 1))    # <= one per 8 games of a pool (two pools): selfplay.default_threads
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
-              "collective": "1 all-reduce of 89 doubles per generation", "host_threads_per_rank": threads,
+              "collective": f"1 all-reduce of {selfplay.STATS_LEN} doubles per generation (scalars + first-move and root-visit histograms)",
+              "host_threads_per_rank": threads, "step_loop": "C (bk_pools_run)" if selfplay.NATIVE_LOOP else "Python (run_pools)",
               "search": "an expansion evaluates its best-prior children only (bk_search_params.eager_top), the rest when a rollout "
                         "reaches it: the same 512 games as with every child evaluated (rounds 1-2), 3.4 M -> 0.6-0.7 M evaluations "
                         "(children_evaluated_per_expansion: fp32 2 from 192 games per rank, else 4; f16x2 6)"}
+        red = torch.device("cuda", local_rank) if backend == "nccl" else None
         # untimed: a small generation first (the pools' worker threads exist, the allocator and the caches are warm)
         selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=min(64 * world, args.selfplay_games), rollouts=50, rank=rank, world=world,
-                           cap=8192, threads=threads, reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-        for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
-            eng.set_precision(prec)
+                           cap=8192, threads=threads, reduce_device=red)
+
+        def generation(n_games, prec):
+            """one generation of n_games games over all ranks: whole-job games/min (max over ranks), what each rank needed, the
+            all-reduce, and the visit / value statistics it sums"""
             ev = selfplay.EngineEvaluator(eng)
             barrier()
-            local, total = selfplay.self_play(ev, n_games=args.selfplay_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
-                                              reduce_device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-            secs = reduce_max(local["seconds"])
-            sp[prec] = {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
-                        "plies": total["plies"], "value_evals": total["value_evals"], "value_evals_per_s": total["value_evals"] / secs,
-                        "children_evaluated_per_expansion": selfplay.default_eager_top(prec, len(selfplay.shard_game_ids(args.selfplay_games, rank, world))),
-                        "black_wins": total["black_wins"], "stats_allreduce_ms": local["allreduce_s"] * 1e3,
-                        "first_move_hist_sum": int(sum(total["first_move_hist"]))}
+            local, total = selfplay.self_play(ev, n_games=n_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
+                                              reduce_device=red)
+            per_rank_s = gather(local["seconds"])
+            reduce_ms = gather(local["allreduce_s"] * 1e3)
+            secs = max(per_rank_s)
+            mine = len(selfplay.shard_game_ids(n_games, rank, world))
+            return {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
+                    "per_rank_seconds": per_rank_s, "per_rank_seconds_min": min(per_rank_s), "per_rank_seconds_max": secs,
+                    "games_per_rank": mine, "plies": total["plies"], "value_evals": total["value_evals"],
+                    "value_evals_per_s": total["value_evals"] / secs,
+                    "children_evaluated_per_expansion": selfplay.default_eager_top(prec, mine),
+                    "black_wins": total["black_wins"], "stats_allreduce_ms": max(reduce_ms), "stats_allreduce_ms_per_rank": reduce_ms,
+                    "first_move_hist_sum": int(sum(total["first_move_hist"])),
+                    # north_star: "all-reduce visit/value statistics at the end of a generation"
+                    "root_visit_hist_sum": int(sum(total["root_visit_hist"])), "root_visit_hist_top5": sorted(
+                        ((go_name(m), int(n)) for m, n in enumerate(total["root_visit_hist"])), key=lambda t: -t[1])[:5],
+                    "mean_root_value": total["mean_root_value"], "mean_abs_root_value": total["mean_abs_root_value"],
+                    "n_root_values": total["n_root_values"], "pools": local["n_pools"], "native_loop": local["native_loop"]}
+
+        def go_name(m):
+            from bokego_amd import go
+            return go.unsquash(m)
+
+        for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
+            eng.set_precision(prec)
+            sp[prec] = generation(args.selfplay_games, prec)          # STRONG scaling: the config's fixed 512 games over all ranks
+        eng.set_precision(args.precision)
+        # WEAK scaling: every rank plays its own full set (what the reference's workers do: cpu_count() processes, each with
+        # its own games, bin/selfplay.py:177-199) -- games x n_gpus in all, `games` per rank, the same one all-reduce at the
+        # end.  At one rank it is the strong leg.  A rank's seconds here are what ONE rank needs for the whole config, so
+        # both efficiencies can be read off this line: weak = min / max of per_rank_seconds against a 1-GPU run's `seconds`;
+        # strong = (a rank's weak-leg seconds) / (n_gpus x the strong leg's seconds).
+        if world > 1:
+            sp["weak"] = dict(generation(args.selfplay_games * world, args.precision), precision=args.precision,
+                              what=f"{args.selfplay_games} games PER RANK ({args.selfplay_games * world} in all), one all-reduce")
+            one_rank = float(np.median(sp["weak"]["per_rank_seconds"]))
+            sp["strong_scaling_efficiency_vs_own_weak_leg"] = one_rank / (world * sp[args.precision]["seconds"])
+            sp["weak_scaling_per_rank_seconds_min_over_max"] = sp["weak"]["per_rank_seconds_min"] / sp["weak"]["per_rank_seconds_max"]
+        else:
+            sp["weak"] = {"same_as": args.precision, "what": "one rank: the weak leg is the strong leg"}
         eng.set_precision(args.precision)
         sp["games_per_min"] = sp[args.precision]["games_per_min"]
         sp["stats_allreduce_ms"] = sp[args.precision]["stats_allreduce_ms"]

@@ -15,7 +15,7 @@ BK_WANT_LOGITS, BK_WANT_PROBS, BK_WANT_VALUE = 1, 2, 4
 BK_FEATS_F32, BK_FEATS_U8 = 0, 1
 BK_MAX_INFLIGHT = 4
 PRECISIONS = {"f32": 0, "f16x2": 1}
-BK_ABI_VERSION = 6
+BK_ABI_VERSION = 7
 
 STATUS_NAMES = {0: "BK_OK", -1: "BK_ERR_ARG", -2: "BK_ERR_HIP", -3: "BK_ERR_OOM", -4: "BK_ERR_BATCH",
                 -5: "BK_ERR_NO_NET", -6: "BK_ERR_NO_GPU"}
@@ -79,19 +79,26 @@ SYMBOLS = {
     "bk_plan_flops": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "bk_engine_synchronize": (ctypes.c_int, [_P]),
+    "bk_engine_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    "bk_engine_get_option": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "bk_has_test_hooks": (ctypes.c_int, []),
+    "bk_engine_evaluator": (ctypes.c_int, [_P, _P]),
     "bk_last_error": (ctypes.c_char_p, [_P]),
 }
 
-_lib = None
+HOOKS_LIB_PATH = os.path.join(_HERE, "libbokego_amd_hooks.so")   # make hooks: the fault-injection build, for tests only
+
+_libs = {}
 
 
-def load():
-    """Load the shared library (raises RuntimeError with build instructions if absent)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load the shared library (raises RuntimeError with build instructions if absent).  path: another build of it
+    (tests/test_gpu_hooks.py loads the -DBK_TEST_HOOKS build beside the shipped one); each path is loaded once."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path not in _libs:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not found: build it with `make -C bokego_amd/csrc` "
+                f"{path} not found: build it with `make -C bokego_amd/csrc` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
         # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HSA
         # runtimes in one process cannot both open the GPU, so make torch's copy the one the
@@ -100,12 +107,12 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
         if lib.bk_abi_version() != BK_ABI_VERSION and not os.environ.get("BK_LIB_ANY_ABI"):  # (tools/ab_bits.py: older builds)
-            raise RuntimeError("libbokego_amd.so ABI version mismatch; rebuild")
-        _lib = lib
-    return _lib
+            raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch; rebuild")
+        _libs[path] = lib
+    return _libs[path]

@@ -153,14 +153,14 @@ class NativeComm:
 
 def _selftest():
     """python -m bokego_amd.comm: one rank of a world-N check of libbkcomm.so (RANK / WORLD_SIZE / LOCAL_RANK and
-    BK_COMM_ID_PATH from the environment): all-reduce of an 89-double vector and a broadcast; prints one JSON line."""
+    BK_COMM_ID_PATH from the environment): all-reduce of a 173-double vector (the self-play statistics' length) and a broadcast; prints one JSON line."""
     import json
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dev = int(os.environ.get("BK_COMM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     t0 = time.perf_counter()
     c = NativeComm.create(rank, world, dev, os.environ.get("BK_COMM_ID_PATH", "/tmp/bk_comm_id"))
     t_init = time.perf_counter() - t0
-    v = (np.arange(89, dtype=np.float64) + 1) * (rank + 1)
+    v = (np.arange(173, dtype=np.float64) + 1) * (rank + 1)
     out = c.allreduce_sum(v)                      # first call: includes RCCL's lazy channel set-up
     t0 = time.perf_counter()
     for _ in range(10):
@@ -168,7 +168,7 @@ def _selftest():
     t_ar = (time.perf_counter() - t0) / 10
     w = np.full(1_000_003, float(rank), np.float32)
     w = c.broadcast_f32(w, root=world - 1)
-    ok = bool(np.array_equal(out, (np.arange(89) + 1) * (world * (world + 1) / 2)) and (w == world - 1).all())
+    ok = bool(np.array_equal(out, (np.arange(173) + 1) * (world * (world + 1) / 2)) and (w == world - 1).all())
     print(json.dumps({"rank": rank, "world": c.world, "ok": ok, "init_s": t_init, "allreduce_ms": t_ar * 1e3}), flush=True)
     c.close()
     return 0 if ok else 1

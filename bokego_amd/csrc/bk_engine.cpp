@@ -21,11 +21,22 @@
 #include <vector>
 
 #include "../../include/bokego_amd.h"
+#include "../../include/bokego_tree.h"   // bk_evaluator (bk_engine_evaluator), bk_pos
 #include "bk_internal.h"
 
 namespace {
 
 thread_local std::string g_create_error;
+
+// The ONE place this file reads the environment, called from bk_engine_create only (and from the marker loader it triggers):
+// every BK_* switch becomes a field of the engine there.  A request never looks at the environment -- getenv is not safe
+// against a concurrent setenv (Python's os.environ[...] = in another thread), and a stray variable in an operator's shell
+// must not change a running engine.  bk_engine_set_option changes a switch of a live engine.
+const char* env_str(const char* name) { return getenv(name); }
+int env_int(const char* name, int dflt) {
+    const char* v = env_str(name);
+    return v && *v ? atoi(v) : dflt;
+}
 
 // roctx ranges around the requests, so that a rocprofv3 --marker-trace timeline shows "bk_submit B=.. np=.." / "bk_wait"
 // above the kernels and copies they enqueue ("roctx ranges around bk_eval").  The marker library is looked up at
@@ -35,7 +46,7 @@ struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        if (!getenv("BK_ROCTX")) return;
+        if (!env_str("BK_ROCTX")) return;
         for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
             if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
                 push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
@@ -219,8 +230,14 @@ struct bk_engine {
     unsigned int* h_redo = nullptr;
     unsigned int* h_redo_dev = nullptr;  // the same block as the GPU addresses it
     unsigned int redo_seen[BK_DEV_FLAGS] = {};
-    // BK_FAULT_SUBMIT=<n> (tests): the n-th HIP call of a ticket submission reports a failure instead of being made
-    int fault_at = 0, fault_seen = 0;
+    // switches (bk_engine_set_option; defaults from the environment, read once at create)
+    bk_plan_opts plan;                   // force_nb, no_split, coop, coop3
+    int no_direct = 0, no_head_part = 0, encode_overlap = 0, copy_threads = 6;
+#ifdef BK_TEST_HOOKS
+    // test builds only (make hooks): the n-th HIP call of every ticket submission (fault_submit), or of anything from now on
+    // (bk_debug_fail_nth_hip_call), reports a failure instead of being made; coop_fault: a cooperative peer deserts
+    int fault_at = 0, fault_seen = 0, fault_submit = 0, coop_fault = 0;
+#endif
     // device-pointer path, f16x2: a ring of BK_DEV_FLAGS words, one per call (call number % BK_DEV_FLAGS), zeroed in stream
     // order in front of the call's f16x2 kernel, which raises it to the call number on overflow: that is what gates the
     // call's fp32 redo kernel.  One word per call, so calls running concurrently on different caller streams cannot hide
@@ -240,12 +257,16 @@ int fail(bk_engine* e, int code, const std::string& msg) {
     if (e) e->err = msg; else g_create_error = msg;
     return code;
 }
-// test hook (BK_FAULT_SUBMIT, armed by submit_common for the length of one submission): true = this HIP call "fails"
+#ifdef BK_TEST_HOOKS
+// test hook (option "fault_submit", armed by submit_common for the length of one submission): true = this HIP call "fails"
 inline bool inject_fault(bk_engine* e) {
     if (!e || e->fault_at <= 0 || ++e->fault_seen != e->fault_at) return false;
     e->fault_at = 0;                                     // one shot
     return true;
 }
+#else
+inline bool inject_fault(bk_engine*) { return false; }
+#endif
 inline void bump(uint64_t& c, uint64_t v = 1) { __atomic_fetch_add(&c, v, __ATOMIC_RELAXED); }
 #define HIP_TRY(e, call)                                                                       \
     do {                                                                                       \
@@ -533,17 +554,17 @@ void drain_events(bk_engine* e, bool wait_oldest = false) {
 // size, or k whole rounds of 3-board workgroups (one per CU) followed by a tail launch whose workgroup size makes the
 // partial last round shortest -- e.g. 1,201 boards = 256 3-board workgroups + 217 2-board ones (1 + 0.77 rounds) instead
 // of 401 3-board ones (2 rounds, the second with 111 CUs idle).  Costs are the measured per-round times.  A pure function
-// of its arguments (and BK_FORCE_NB / BK_NO_SPLIT): enqueue() launches by it, bk_plan_flops() prices it.
+// of its arguments: enqueue() launches by it (with the engine's switches), bk_plan_flops() prices it (with the defaults).
 struct LaunchPlan {
     int nb1;                       // single launch: boards per workgroup
     int head_p, head_v, tail_nb;   // tail_nb != 0: head_p + head_v 3-board workgroups first, the rest as tail_nb-board ones
 };
-LaunchPlan plan_launch(int B_policy, int B_value, int n_cu, int precision) {
-    LaunchPlan pl{bk_pick_nb(B_policy, B_value, n_cu, precision), 0, 0, 0};
+LaunchPlan plan_launch(int B_policy, int B_value, int n_cu, int precision, const bk_plan_opts& o = bk_plan_opts()) {
+    LaunchPlan pl{bk_pick_nb(B_policy, B_value, n_cu, precision, o), 0, 0, 0};
     const long single = bk_launch_cost(B_policy, B_value, pl.nb1, n_cu, precision);
     long best = single;
     const int full_p = B_policy / 3, full_v = B_value / 3;   // complete 3-board workgroups per net
-    if (!getenv("BK_FORCE_NB") && !getenv("BK_NO_SPLIT")) {
+    if (!o.force_nb && !o.no_split) {
         for (long k = 1; k * n_cu <= full_p + full_v; ++k) {
             const long head = k * n_cu;
             int hp = (int)std::min<long>(full_p, (head * full_p / (full_p + full_v)) & ~3L);  // keep the 4-block XCD pairing
@@ -551,7 +572,7 @@ LaunchPlan plan_launch(int B_policy, int B_value, int n_cu, int precision) {
             if (hv > full_v) { hv = full_v; hp = (int)(head - hv); }
             const int rp = B_policy - 3 * hp, rv = B_value - 3 * hv;
             if (rp + rv == 0) break;
-            const int nbt = bk_pick_nb(rp, rv, n_cu, precision);
+            const int nbt = bk_pick_nb(rp, rv, n_cu, precision, o);
             const long cost = k * 100 + bk_launch_cost(rp, rv, nbt, n_cu, precision) + (precision == BK_PRECISION_F16X2 ? 4 : 1);  // + a second launch's overhead
             // worth it from 3 % (f16x2: power-limited, the idle CUs of a ragged last round let the busy ones clock higher)
             // resp. 1 % (fp32: issue-limited at full clock, a shorter last round is a shorter launch)
@@ -631,15 +652,17 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // Small batches of the ticket path (engine's own stream, one exchange buffer): several CUs per board (bk_kernels.hip,
     // "cooperative form").  A workgroup that gives up waiting for its peers raises word 1 of the slot's flag block, which
     // travels to the host with the outputs: bk_wait then redoes the request with the one-CU form.
-    const bool coop_ok = allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag && !getenv("BK_FORCE_NB");
-    int coop_form = coop_ok ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu) : 0;
-    if (coop_ok && !coop_form) coop_form = bk_coop3_form(a.B_policy, a.B_value, e->n_cu);   // three boards on 2 / 4 CUs
+    const bool coop_ok = allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag && !e->plan.force_nb;
+    int coop_form = coop_ok ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu, e->plan) : 0;
+    if (coop_ok && !coop_form) coop_form = bk_coop3_form(a.B_policy, a.B_value, e->n_cu, e->plan);   // three boards on 2 / 4 CUs
     if (const int slices = coop_form) {
         a.coop_xchg = e->d_coop_xchg;
         a.coop_sync = e->d_coop_sync;
         a.coop_err = d_flag + 1;
         a.coop_tag = 1;
-        a.coop_fault = getenv("BK_COOP_FAULT") != nullptr;
+#ifdef BK_TEST_HOOKS
+        a.coop_fault = e->coop_fault;
+#endif
         HIP_TRY(e, bk_launch_leaf_eval_coop(a, slices, stream));
         bump(e->st.coop_launches);
         if (const int trc = close_timing()) return trc;
@@ -648,7 +671,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
         if ((uint64_t)B > e->st.max_batch_seen) e->st.max_batch_seen = (uint64_t)B;
         return BK_OK;
     }
-    const LaunchPlan pl = plan_launch(cnt_p, cnt_v, e->n_cu, precision);
+    const LaunchPlan pl = plan_launch(cnt_p, cnt_v, e->n_cu, precision, e->plan);
     const int nb1 = pl.nb1, head_p = pl.head_p, head_v = pl.head_v, tail_nb = pl.tail_nb;
     if (tail_nb) {
         bk_eval_args h = a;
@@ -703,7 +726,17 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->has_policy = policy != nullptr;
     e->has_value = value != nullptr;
     e->precision = BK_PRECISION_F32;  // default: the reference's arithmetic width (torch fp32); f16x2 is opt-in
-    if (const char* pz = getenv("BK_PRECISION")) e->precision = std::string(pz) == "f16x2" ? BK_PRECISION_F16X2 : BK_PRECISION_F32;
+    // the environment is read here and nowhere else (see env_str): BK_PRECISION and the diagnostic switches
+    if (const char* pz = env_str("BK_PRECISION")) e->precision = std::string(pz) == "f16x2" ? BK_PRECISION_F16X2 : BK_PRECISION_F32;
+    e->plan.force_nb = env_int("BK_FORCE_NB", 0);
+    e->plan.no_split = env_str("BK_NO_SPLIT") != nullptr;
+    e->plan.coop = env_int("BK_COOP", -1);
+    e->plan.coop3 = env_int("BK_COOP3", -1);
+    e->no_direct = env_str("BK_NO_DIRECT") != nullptr;
+    e->no_head_part = env_str("BK_NO_HEAD_PART") != nullptr;
+    e->encode_overlap = env_str("BK_ENCODE_OVERLAP") != nullptr;
+    e->copy_threads = env_int("BK_COPY_THREADS", 6);
+    (void)roctx();                                           // BK_ROCTX: the marker library is looked up now, not by the first request
     int rc = BK_OK;
     auto bail = [&](int code) {
         g_create_error = e->err;
@@ -841,12 +874,16 @@ int64_t submit_common(bk_engine* e, const void* src, int src_kind, int B, int n_
         if (!c.busy) { s = &c; break; }
     if (!s) return fail(e, BK_ERR_ARG, "more than BK_MAX_INFLIGHT tickets outstanding");
     HIP_TRY(e, hipSetDevice(e->device));
-    if (const char* f = getenv("BK_FAULT_SUBMIT")) {      // tests: the n-th HIP call of this submission fails
-        e->fault_at = atoi(f);
+#ifdef BK_TEST_HOOKS
+    if (e->fault_submit > 0) {                            // tests: the n-th HIP call of this submission fails
+        e->fault_at = e->fault_submit;
         e->fault_seen = 0;
     }
+#endif
     const int64_t t = submit_body(e, s, src, src_kind, B, n_policy, want, logits, probs, values);
+#ifdef BK_TEST_HOOKS
     e->fault_at = 0;
+#endif
     if (t < 0) abort_submission(e, s);
     return t;
 }
@@ -866,12 +903,11 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
     // reads after the request's event.  Two of the five enqueues and ~12 us of copy kernels per round trip disappear
     // (rocprofv3 timeline, profiles/r03_genmove_timeline.md).  fp32 only: the f16x2 kernel's overflow flag is raised with
     // an atomic max, which is not used on host memory here.  BK_NO_DIRECT=1 restores the copies.
-    const bool direct = !chained && B > 0 && e->precision == BK_PRECISION_F32 && s->h_in_dev && s->h_out_dev && !getenv("BK_NO_DIRECT");
+    const bool direct = !chained && B > 0 && e->precision == BK_PRECISION_F32 && s->h_in_dev && s->h_out_dev && !e->no_direct;
     s->direct = direct;
     if (B > 0) {
         void* d_dst = src_kind == kSrcPositions ? s->d_pos : s->d_in;
-        const char* ct_env = bytes >= ((size_t)4 << 20) ? getenv("BK_COPY_THREADS") : nullptr;
-        const int copy_threads = ct_env ? atoi(ct_env) : 6;
+        const int copy_threads = e->copy_threads;
         // bytes [b0, b1) of the request: host buffer -> pinned slot -> device, on the copy-in stream
         auto stage = [&](size_t b0, size_t b1) -> int {
             const size_t n = b1 - b0;
@@ -902,7 +938,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
         // then costs the kernel plus ~0.2 ms instead of plus 1.3 ms.  Results do not depend on how a request is launched.
         constexpr int kHeadRows = 768;
         const size_t row_bytes = bytes / (size_t)B;
-        const bool two_part = chained && src_kind != kSrcPositions && B >= 3 * kHeadRows && bytes >= ((size_t)16 << 20) && !getenv("BK_NO_HEAD_PART");
+        const bool two_part = chained && src_kind != kSrcPositions && B >= 3 * kHeadRows && bytes >= ((size_t)16 << 20) && !e->no_head_part;
         if (direct && src_kind == kSrcPositions) {
             std::memcpy(s->h_in, src, bytes);          // the encoder reads the records from here
         } else if (two_part) {
@@ -916,7 +952,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
         // launched it on the copy-in stream so that it overlapped the previous request's leaf kernel; under that
         // kernel its workgroups wait for CUs, so it "ran" 110-370 us per call (6-8 % of the summed kernel time of a
         // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  BK_ENCODE_OVERLAP=1 restores that.
-        static const bool enc_overlap = getenv("BK_ENCODE_OVERLAP") != nullptr;
+        const bool enc_overlap = e->encode_overlap != 0;
         if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
             HIP_TRY(e, bk_launch_encode(direct ? s->h_in_dev : s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             bump(e->st.positions_encoded, (uint64_t)B);
@@ -1190,14 +1226,76 @@ int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* 
     return BK_OK;
 }
 
-// test hook (not part of include/bokego_amd.h; tests/test_gpu_engine_hygiene.py): the n-th HIP call the engine makes from now
-// on reports a failure instead of being made, once.  BK_FAULT_SUBMIT arms the same counter for one ticket submission.
+int bk_has_test_hooks(void) {
+#ifdef BK_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+namespace {
+int* option_field(bk_engine* e, const std::string& n) {
+    if (n == "force_nb") return &e->plan.force_nb;
+    if (n == "no_split") return &e->plan.no_split;
+    if (n == "coop") return &e->plan.coop;
+    if (n == "coop3") return &e->plan.coop3;
+    if (n == "no_direct") return &e->no_direct;
+    if (n == "no_head_part") return &e->no_head_part;
+    if (n == "encode_overlap") return &e->encode_overlap;
+    if (n == "copy_threads") return &e->copy_threads;
+#ifdef BK_TEST_HOOKS
+    if (n == "coop_fault") return &e->coop_fault;
+    if (n == "fault_submit") return &e->fault_submit;
+#endif
+    return nullptr;
+}
+}  // namespace
+
+int bk_engine_set_option(bk_engine* e, const char* name, int value) {
+    if (!e || !name) return BK_ERR_ARG;
+    int* f = option_field(e, name);
+    if (!f) return fail(e, BK_ERR_ARG, std::string("unknown engine option '") + name + "'");
+    *f = value;
+    return BK_OK;
+}
+
+int bk_engine_get_option(bk_engine* e, const char* name, int* value) {
+    if (!e || !name || !value) return BK_ERR_ARG;
+    const int* f = option_field(e, name);
+    if (!f) return fail(e, BK_ERR_ARG, std::string("unknown engine option '") + name + "'");
+    *value = *f;
+    return BK_OK;
+}
+
+/* the engine as the evaluator of the native step loop (include/bokego_tree.h, bk_pools_run) */
+namespace {
+int64_t evaluator_submit(void* ctx, const bk_pos* recs, int B, int n_policy, float* probs, float* values) {
+    bk_engine* e = static_cast<bk_engine*>(ctx);
+    const int want = (n_policy > 0 && e->has_policy ? BK_WANT_PROBS : 0) | (e->has_value ? BK_WANT_VALUE : 0);
+    return bk_submit_positions(e, recs, B, n_policy, want, nullptr, probs, values);
+}
+int evaluator_wait(void* ctx, int64_t ticket) { return bk_wait(static_cast<bk_engine*>(ctx), ticket); }
+}  // namespace
+
+int bk_engine_evaluator(bk_engine* e, bk_evaluator* out) {
+    if (!e || !out) return BK_ERR_ARG;
+    out->ctx = e;
+    out->submit = evaluator_submit;
+    out->wait = evaluator_wait;
+    return BK_OK;
+}
+
+#ifdef BK_TEST_HOOKS
+// test builds only (not part of include/bokego_amd.h; tests/test_gpu_hooks.py): the n-th HIP call the engine makes from now
+// on reports a failure instead of being made, once.  The option "fault_submit" arms the same counter for every ticket submission.
 int bk_debug_fail_nth_hip_call(bk_engine* e, int n) {
     if (!e) return BK_ERR_ARG;
     e->fault_at = n;
     e->fault_seen = 0;
     return BK_OK;
 }
+#endif
 
 #ifdef BK_STAMPS
 // diagnostic builds only (not part of include/bokego_amd.h)

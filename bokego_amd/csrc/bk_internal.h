@@ -67,7 +67,7 @@ struct bk_eval_args {
     unsigned int* coop_sync;
     unsigned int* coop_err;
     unsigned int coop_tag;
-    int coop_fault;              // tests (env BK_COOP_FAULT): slice 1 of task 0 leaves before layer 3's meeting point
+    int coop_fault;              // -DBK_TEST_HOOKS builds only (option "coop_fault"): slice 1 of task 0 leaves before layer 3's meeting point
     unsigned long long* stamps;  // diagnostic builds (-DBK_STAMPS) only: [block][wave][32] s_memtime
 };
 
@@ -83,7 +83,16 @@ static inline int bk_slot_perm(int s) { return (s & ~15) | (((s >> 1) & 1) << 3)
 // feature planes [B][27][9][9] u8 from B position records (bk_encode.hip)
 hipError_t bk_launch_encode(const void* d_pos, int B, uint8_t* d_planes, hipStream_t stream);
 
-int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision);
+// What used to be read from the environment on every request (BK_FORCE_NB, BK_NO_SPLIT, BK_COOP, BK_COOP3): the launch planner's
+// switches, held per engine (read from the environment ONCE, in bk_engine_create; bk_engine_set_option changes them on a live
+// engine).  The pure planner entry points of the C ABI (bk_plan_query / bk_plan_flops) use the defaults.
+struct bk_plan_opts {
+    int force_nb = 0;    // 1..3: every whole-board launch uses workgroups of that many boards
+    int no_split = 0;    // 1: never k whole rounds + a tail launch
+    int coop = -1;       // -1: by task count; 0: no cooperative launch of either kind; 2/3/4/6/8/12: that many CUs per board where it fits
+    int coop3 = -1;      // -1: by task count; 0: no three-boards form; 2 / 4: that form where it fits
+};
+int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision, const bk_plan_opts& o = bk_plan_opts());
 long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision);  // modelled time of one launch (arbitrary units)
 hipError_t bk_launch_leaf_eval(const bk_eval_args& a, int nb, hipStream_t stream);
 double bk_coop_mfma_flop_per_task(int slices);   // ... of one task in the cooperative form with `slices` CUs per board
@@ -96,7 +105,7 @@ double bk_mfma_flop_per_workgroup(int nb);   // fp32 kernel: executed MFMA FLOP 
 // runs through without waiting for anybody: the counters it would meet at are not trustworthy, and its outputs are redone too.
 #define BK_COOP_POISON_WORD (BK_COOP_MAX_TASKS * BK_COOP_SYNC_STRIDE)
 #define BK_COOP_SYNC_WORDS (BK_COOP_POISON_WORD + BK_COOP_SYNC_STRIDE)
-int bk_coop_slices(int tasks, int n_cu);   // 0: not a cooperative case
+int bk_coop_slices(int tasks, int n_cu, const bk_plan_opts& o = bk_plan_opts());   // 0: not a cooperative case
 // three boards of one net on 2 / 4 CUs (bk_kernels.hip, bk_leaf_eval_coop3_kernel): form codes beside the one-board form's 2..12
 #define BK_COOP3_FORM_2 102
 #define BK_COOP3_FORM_4 104
@@ -104,6 +113,6 @@ int bk_coop_slices(int tasks, int n_cu);   // 0: not a cooperative case
 #define BK_COOP3_FORM_4_MAX 192                       // tasks: up to here four CUs per three boards ...
 #define BK_COOP3_FORM_2_MAX 384                       // ... and two up to here (beyond: whole-board workgroups)
 #define BK_COOP_XCHG_BYTES ((size_t)BK_COOP3_MAX_GROUPS * 2 * 243 * 128 * 4)   // the exchange buffer serves both forms
-int bk_coop3_form(int B_policy, int B_value, int n_cu);   // 0 / BK_COOP3_FORM_2 / BK_COOP3_FORM_4
+int bk_coop3_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o = bk_plan_opts());   // 0 / BK_COOP3_FORM_2 / BK_COOP3_FORM_4
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -873,7 +873,9 @@ __global__ void __launch_bounds__((CoopTiles<SC, SR, RH>::THREADS)) bk_leaf_eval
         STAMP(3 + 4 * L);
         __syncthreads();
         const bool last = L == 6;
+#ifdef BK_TEST_HOOKS
         if (a.coop_fault && L == 3 && task == 0 && slice == 1) return false;   // test hook: a peer that never arrives
+#endif
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(last && slice != 0) && !dead) {
@@ -1074,7 +1076,9 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const bool last = L == 6;
+#ifdef BK_TEST_HOOKS
         if (a.coop_fault && L == 3 && grp == 0 && sc == 1) return false;   // test hook: a peer that never arrives
+#endif
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(last && sc != 0) && !dead) {
@@ -1225,11 +1229,8 @@ long bk_launch_cost(int B_policy, int B_value, int nb, int n_cu, int precision) 
     return (wgs + n_cu - 1) / n_cu * (precision == BK_PRECISION_F16X2 ? t16 : t32)[nb];
 }
 
-int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
-    if (const char* f = getenv("BK_FORCE_NB")) {
-        const int v = atoi(f);
-        if (v >= 1 && v <= 3) return v;
-    }
+int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision, const bk_plan_opts& o) {
+    if (o.force_nb >= 1 && o.force_nb <= 3) return o.force_nb;
     int best = 3;
     long best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {
@@ -1240,10 +1241,10 @@ int bk_pick_nb(int B_policy, int B_value, int n_cu, int precision) {
 }
 
 // slices per board of the cooperative form for `tasks` one-board tasks on n_cu CUs; 0: use the ordinary forms
-int bk_coop_slices(int tasks, int n_cu) {
-    if (tasks <= 0 || tasks > BK_COOP_MAX_TASKS) return 0;
-    if (const char* f = getenv("BK_COOP")) {
-        const int v = atoi(f);
+int bk_coop_slices(int tasks, int n_cu, const bk_plan_opts& o) {
+    if (tasks <= 0 || tasks > BK_COOP_MAX_TASKS || o.force_nb) return 0;
+    if (o.coop >= 0) {
+        const int v = o.coop;
         if (v == 0) return 0;
         if ((v == 2 || v == 3 || v == 4 || v == 6 || v == 8 || v == 12) && (tasks + 7) / 8 * 8 * v <= 2 * n_cu) return v;
     }
@@ -1261,15 +1262,13 @@ int bk_coop_slices(int tasks, int n_cu) {
 
 // three boards on 2 / 4 CUs for the requests between the whole-board forms' ranges; 0: use the ordinary forms.
 // Groups (three boards of one net) are dealt to the XCDs like the one-board form's tasks: ceil(groups / 8) x SC CUs of one XCD.
-int bk_coop3_form(int B_policy, int B_value, int n_cu) {
+int bk_coop3_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o) {
     const int tasks = B_policy + B_value, groups = (B_policy + 2) / 3 + (B_value + 2) / 3;
     if (tasks <= 0 || groups > BK_COOP3_MAX_GROUPS) return 0;
     const int per_xcd = (groups + 7) / 8, cus = n_cu / 8;
-    if (const char* f = getenv("BK_COOP")) {
-        if (atoi(f) == 0) return 0;                     // BK_COOP=0: no cooperative launch of either kind
-    }
-    if (const char* f = getenv("BK_COOP3")) {
-        const int v = atoi(f);
+    if (o.coop == 0 || o.force_nb) return 0;            // coop = 0: no cooperative launch of either kind
+    if (o.coop3 >= 0) {
+        const int v = o.coop3;
         if (v == 0) return 0;
         if ((v == 2 || v == 4) && per_xcd * v <= cus) return v == 2 ? BK_COOP3_FORM_2 : BK_COOP3_FORM_4;
     }

@@ -116,6 +116,13 @@ struct Game {
     std::vector<std::vector<std::pair<int16_t, int32_t>>> visit_log;  // per ply: (move, N) of the root's children
     uint64_t n_value_evals = 0, n_policy_evals = 0, n_requests = 0;
     float final_score = 0.f;
+    // visit / value statistics of the moves chosen so far (bk_pool_game_stats; the end-of-generation all-reduce sums them):
+    // root_visits[m] = sum over the plies played of the visit count of the root's child for move m when the ply was chosen;
+    // root values = V[root] / N[root] at that moment (what MCTS.winrate reads, mcts.py:159-170: 2 winrate - 1, side to move),
+    // summed in 2^-32 fixed point so that the totals do not depend on the order games are added up in
+    uint64_t root_visits[81] = {0};
+    int64_t sum_root_value_q = 0, sum_abs_root_value_q = 0;
+    uint64_t n_root_values = 0;
     bool manual = false;  // driven from outside: rollouts are added, moves chosen/played by the caller
     // MCTS.rollout(n, analyze_dict) (mcts.py:143-147): while on, every descent longer than two nodes is remembered
     // under the root child it went through (path[1] -> path[1:]; a later descent through the same child replaces it)
@@ -511,6 +518,20 @@ struct Game {
         for (int i = 0; i < 81; ++i) p[i] = (double)((1.f - w) * (float)p[i] + w * (float)(g[i] / sum));
     }
 
+    void note_choice() {  // the root's statistics at the moment a move is chosen (see root_visits)
+        const TNode& r = nodes[root];
+        for (int i = 0; i < r.n_kids; ++i) {
+            const TNode& k = nodes[kid_ids[r.kids_off + i]];
+            if (k.mv >= 0 && k.mv < 81) root_visits[k.mv] += (uint64_t)k.N;
+        }
+        if (r.N > 0) {
+            const int64_t q = (int64_t)std::llround(r.V / (double)r.N * 4294967296.0);
+            sum_root_value_q += q;
+            sum_abs_root_value_q += q < 0 ? -q : q;
+            n_root_values += 1;
+        }
+    }
+
     int pick_move() {  // most visited child, lowest move index on ties (mcts.py:122-128); early plies sampled
         const TNode& r = nodes[root];
         const int* kids = &kid_ids[r.kids_off];
@@ -712,6 +733,7 @@ struct Game {
                     break;
                 case S_CHOOSE: {
                     const int best = pick_move();
+                    note_choice();
                     if (prm.record_visits) {
                         visit_log.emplace_back();
                         const TNode& r = nodes[root];
@@ -1438,6 +1460,7 @@ int bk_pool_choose(bk_pool* p, int g) {  // MCTS.choose at the root (mcts.py:110
     Game& gm = p->games[g];
     if (gm.root < 0 || gm.has_request() || gm.nodes[gm.root].terminal || gm.nodes[gm.root].n_kids == 0) return BK_NO_MOVE;
     const int best = gm.pick_move();
+    gm.note_choice();
     gm.moves.push_back((int16_t)gm.nodes[best].mv);
     const int mv = gm.nodes[best].mv;
     gm.reroot(best);
@@ -1577,6 +1600,258 @@ int bk_pool_root_children(const bk_pool* p, int g, int16_t* moves, int32_t* N, d
         V[i] = k.V;
     }
     return r.n_kids;
+}
+
+
+int bk_pool_game_stats(const bk_pool* p, int g, bk_game_stats* out) {
+    if (g < 0 || g >= (int)p->games.size() || !out) return -1;
+    const Game& gm = p->games[g];
+    std::memcpy(out->root_visits, gm.root_visits, sizeof gm.root_visits);
+    out->sum_root_value = (double)gm.sum_root_value_q / 4294967296.0;          // exact: |q| < 2^53
+    out->sum_abs_root_value = (double)gm.sum_abs_root_value_q / 4294967296.0;
+    out->n_root_values = gm.n_root_values;
+    return 0;
+}
+
+/* ---- snapshot / restore of one game's tree (MCTS.__getstate__ / __setstate__ / __deepcopy__, mcts.py:81-108) ---- */
+}  // extern "C"
+
+namespace {
+constexpr uint32_t kSnapMagic = 0x31544B42u;   // "BKT1"
+constexpr uint32_t kSnapVersion = 1;
+struct SnapWriter {
+    std::vector<uint8_t> b;
+    void raw(const void* p, size_t n) { const uint8_t* q = static_cast<const uint8_t*>(p); b.insert(b.end(), q, q + n); }
+    template <typename T> void pod(const T& v) { raw(&v, sizeof(T)); }
+    template <typename T> void vec(const std::vector<T>& v) {
+        const uint64_t n = v.size();
+        pod(n);
+        if (n) raw(v.data(), n * sizeof(T));
+    }
+    void map(const std::unordered_map<int, std::vector<int>>& m) {
+        std::vector<int> keys;
+        for (const auto& kv : m) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());                 // equal trees give equal bytes
+        const uint64_t n = keys.size();
+        pod(n);
+        for (int k : keys) { pod(k); vec(m.at(k)); }
+    }
+};
+struct SnapReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool ok = true;
+    bool raw(void* dst, size_t n) {
+        if (!ok || (size_t)(end - p) < n) return ok = false;
+        std::memcpy(dst, p, n);
+        p += n;
+        return true;
+    }
+    template <typename T> bool pod(T& v) { return raw(&v, sizeof(T)); }
+    template <typename T> bool vec(std::vector<T>& v) {
+        uint64_t n = 0;
+        if (!pod(n) || n > (uint64_t)(end - p) / sizeof(T)) return ok = false;
+        v.resize((size_t)n);
+        return n == 0 || raw(v.data(), (size_t)n * sizeof(T));
+    }
+    bool map(std::unordered_map<int, std::vector<int>>& m) {
+        uint64_t n = 0;
+        if (!pod(n) || n > (uint64_t)(end - p)) return ok = false;
+        m.clear();
+        for (uint64_t i = 0; i < n && ok; ++i) {
+            int k = 0;
+            std::vector<int> v;
+            if (pod(k) && vec(v)) m.emplace(k, std::move(v));
+        }
+        return ok;
+    }
+};
+
+void snapshot_game(const Game& gm, SnapWriter& w) {
+    w.pod(kSnapMagic);
+    w.pod(kSnapVersion);
+    const uint32_t sizes[3] = {(uint32_t)sizeof(TNode), (uint32_t)sizeof(bk_pos), (uint32_t)sizeof(bk_search_params)};
+    w.pod(sizes);
+    w.pod(gm.prm);
+    w.vec(gm.nodes);
+    w.vec(gm.poses);
+    w.vec(gm.Qs);
+    w.vec(gm.kid_ids);
+    w.vec(gm.priors);
+    const int32_t ints[8] = {gm.root, (int32_t)gm.state, gm.remaining, gm.pending_expand, gm.po, gm.po_mark, gm.po_reward, gm.row_cap};
+    w.pod(ints);
+    w.vec(gm.path);
+    w.vec(gm.req_policy);
+    w.vec(gm.req_value);
+    w.vec(gm.spec_queue);
+    w.vec(gm.spill);
+    w.map(gm.spec_kids);
+    w.map(gm.variations);
+    w.vec(gm.po_priors);
+    w.pod(gm.rng.s);
+    w.vec(gm.moves);
+    const uint64_t nlog = gm.visit_log.size();
+    w.pod(nlog);
+    for (const auto& ply : gm.visit_log) w.vec(ply);
+    const uint64_t cnt[3] = {gm.n_value_evals, gm.n_policy_evals, gm.n_requests};
+    w.pod(cnt);
+    w.pod(gm.final_score);
+    const uint8_t flags[2] = {(uint8_t)gm.manual, (uint8_t)gm.analyze};
+    w.pod(flags);
+    w.pod(gm.root_visits);
+    const int64_t vq[2] = {gm.sum_root_value_q, gm.sum_abs_root_value_q};
+    w.pod(vq);
+    w.pod(gm.n_root_values);
+}
+
+// false: the bytes are not a snapshot this build can take (the game is left untouched)
+bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
+    SnapReader r{buf, buf + len};
+    uint32_t magic = 0, version = 0, sizes[3] = {0, 0, 0};
+    if (!r.pod(magic) || !r.pod(version) || !r.pod(sizes) || magic != kSnapMagic || version != kSnapVersion ||
+        sizes[0] != sizeof(TNode) || sizes[1] != sizeof(bk_pos) || sizes[2] != sizeof(bk_search_params))
+        return false;
+    bk_search_params prm;
+    if (!r.pod(prm)) return false;
+    Game gm(prm, 0);
+    int32_t ints[8];
+    r.vec(gm.nodes); r.vec(gm.poses); r.vec(gm.Qs); r.vec(gm.kid_ids); r.vec(gm.priors);
+    if (!r.pod(ints)) return false;
+    gm.root = ints[0]; gm.state = (State)ints[1]; gm.remaining = ints[2]; gm.pending_expand = ints[3];
+    gm.po = ints[4]; gm.po_mark = ints[5]; gm.po_reward = ints[6]; gm.row_cap = ints[7];
+    r.vec(gm.path); r.vec(gm.req_policy); r.vec(gm.req_value); r.vec(gm.spec_queue); r.vec(gm.spill);
+    r.map(gm.spec_kids); r.map(gm.variations); r.vec(gm.po_priors);
+    r.pod(gm.rng.s);
+    r.vec(gm.moves);
+    uint64_t nlog = 0;
+    if (!r.pod(nlog) || nlog > len) return false;
+    gm.visit_log.resize((size_t)nlog);
+    for (auto& ply : gm.visit_log) r.vec(ply);
+    uint64_t cnt[3];
+    uint8_t flags[2];
+    int64_t vq[2];
+    r.pod(cnt); r.pod(gm.final_score); r.pod(flags); r.pod(gm.root_visits); r.pod(vq); r.pod(gm.n_root_values);
+    if (!r.ok || r.p != r.end) return false;
+    gm.n_value_evals = cnt[0]; gm.n_policy_evals = cnt[1]; gm.n_requests = cnt[2];
+    gm.manual = flags[0] != 0; gm.analyze = flags[1] != 0;
+    gm.sum_root_value_q = vq[0]; gm.sum_abs_root_value_q = vq[1];
+    // every index the search will follow must point inside the arrays it indexes
+    const int n = (int)gm.nodes.size();
+    auto node_ok = [&](int id) { return id >= 0 && id < n; };
+    auto all_ok = [&](const std::vector<int>& v) { return std::all_of(v.begin(), v.end(), node_ok); };
+    if (gm.poses.size() != gm.nodes.size() || (gm.prm.simulate ? gm.Qs.size() != gm.nodes.size() : !gm.Qs.empty())) return false;
+    if (gm.state < S_INIT || gm.state > S_IDLE || gm.remaining < 0) return false;
+    if (n == 0 ? gm.root != -1 : !node_ok(gm.root)) return false;
+    if (gm.pending_expand != -1 && !node_ok(gm.pending_expand)) return false;
+    if (gm.po != -1 || gm.po_mark != -1 || !gm.po_priors.empty()) return false;       // never in the middle of a playout
+    if (!all_ok(gm.kid_ids) || !all_ok(gm.path) || !all_ok(gm.req_policy) || !all_ok(gm.req_value) || !all_ok(gm.spec_queue) || !all_ok(gm.spill)) return false;
+    for (const auto* m : {&gm.spec_kids, &gm.variations})
+        for (const auto& kv : *m)
+            if (!node_ok(kv.first) || !all_ok(kv.second)) return false;
+    if (gm.priors.size() % 81) return false;
+    for (const TNode& nd : gm.nodes) {
+        if (nd.n_kids < 0 || nd.kids_off < 0 || (size_t)nd.kids_off + (size_t)nd.n_kids > gm.kid_ids.size()) return false;
+        if (nd.has_prior && (nd.prior_off < 0 || (size_t)nd.prior_off + 81 > gm.priors.size())) return false;
+        // a node with children is selected through its priors and its children's moves: both must be there
+        // (an expansion whose policy row is still in the request list is the one exception)
+        if (nd.n_kids > 0 && !nd.has_prior &&
+            std::find(gm.req_policy.begin(), gm.req_policy.end(), (int)(&nd - gm.nodes.data())) == gm.req_policy.end()) return false;
+        for (int k = 0; k < nd.n_kids; ++k) {
+            const int mv = gm.nodes[gm.kid_ids[nd.kids_off + k]].mv;
+            if (mv < 0 || mv >= 81) return false;
+        }
+    }
+    gm.table_rebuild(gm.nodes.size());
+    dst = std::move(gm);
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+long bk_pool_snapshot(const bk_pool* p, int g, void* buf, long cap) {
+    if (!p || g < 0 || g >= (int)p->games.size()) return -1;
+    const Game& gm = p->games[g];
+    if (gm.has_request() || gm.po >= 0 || gm.po_mark >= 0) return -2;      // between a deliver and the next collect only
+    SnapWriter w;
+    snapshot_game(gm, w);
+    if (buf && cap >= (long)w.b.size()) std::memcpy(buf, w.b.data(), w.b.size());
+    return (long)w.b.size();
+}
+
+int bk_pool_restore(bk_pool* p, int g, const void* buf, long len) {
+    if (!p || g < 0 || g >= (int)p->games.size() || !buf || len <= 0) return -1;
+    if (p->games[g].has_request()) return -2;
+    for (int a : p->active)
+        if (a == g) return -2;
+    Game& dst = p->games[g];
+    const int row_cap = p->row_cap > 0 ? p->row_cap : dst.row_cap;
+    if (!restore_game(dst, static_cast<const uint8_t*>(buf), (size_t)len)) return -3;
+    dst.row_cap = std::min(dst.row_cap, row_cap);                 // the receiving pool's collects may be smaller
+    dst.prm.speculate_rows = std::min(dst.prm.speculate_rows, dst.row_cap);
+    return 0;
+}
+
+/* ---- the step loop in C (selfplay.py:run_pools without the interpreter between two steps) ---- */
+void bk_normalise_rows(float* probs, int n_rows) {
+    for (int r = 0; r < n_rows; ++r) {
+        float* row = probs + (size_t)81 * r;
+        float sum = 0.f;
+        for (int k = 0; k < 81; ++k) sum += row[k];                // left to right, fp32: the order is part of the contract
+        for (int k = 0; k < 81; ++k) row[k] /= sum;
+    }
+}
+
+int bk_pools_run(bk_pool* const* pools, int n_pools, const bk_evaluator* ev, int cap, bk_run_info* out) {
+    if (!pools || n_pools <= 0 || n_pools > 16 || !ev || !ev->submit || !ev->wait || cap < 82) return -1;
+    struct Lane {
+        std::vector<bk_pos> recs;
+        std::vector<float> probs, values;
+        int64_t ticket = 0;
+        int n = 0, npol = 0;
+        bool live = true;
+    };
+    std::vector<Lane> lanes((size_t)n_pools);
+    for (auto& l : lanes) {
+        l.recs.resize((size_t)cap);
+        l.probs.resize((size_t)cap * 81);
+        l.values.resize((size_t)cap);
+    }
+    bk_run_info info{};
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    for (bool busy = true; busy && !rc;) {
+        busy = false;
+        for (int i = 0; i < n_pools && !rc; ++i) {
+            Lane& l = lanes[(size_t)i];
+            if (l.ticket) {
+                const auto w0 = std::chrono::steady_clock::now();
+                const int wrc = ev->wait(ev->ctx, l.ticket);
+                info.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                if (wrc) { rc = wrc < 0 ? wrc : -wrc; break; }
+                bk_normalise_rows(l.probs.data(), l.npol);          // Categorical(probs) re-normalises (nnet.py:274)
+                bk_pool_deliver(pools[i], l.probs.data(), l.values.data());
+                l.ticket = 0;
+            }
+            if (l.live) {
+                l.n = bk_pool_collect_pos(pools[i], l.recs.data(), cap, &l.npol);
+                if (l.n == 0) { l.live = false; continue; }
+                l.ticket = ev->submit(ev->ctx, l.recs.data(), l.n, l.npol, l.probs.data(), l.values.data());
+                if (l.ticket <= 0) { rc = l.ticket < 0 ? (int)l.ticket : -1; l.ticket = 0; break; }
+                info.steps += 1;
+                info.rows += (uint64_t)l.n;
+                info.policy_rows += (uint64_t)l.npol;
+                busy = true;
+            }
+            busy = busy || l.ticket != 0;
+        }
+    }
+    if (rc)                                   // requests still out: wait for them so that the evaluator's buffers can go
+        for (auto& l : lanes)
+            if (l.ticket) (void)ev->wait(ev->ctx, l.ticket);
+    info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out) *out = info;
+    return rc;
 }
 
 }  // extern "C"

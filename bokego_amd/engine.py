@@ -54,10 +54,11 @@ _HEAD_KEYS = (("bn_w", "bn.weight", 1), ("bn_b", "bn.bias", 1), ("bn_mean", "bn.
 class LeafEngine:
     """policy_sd / value_sd: mappings with the reference state_dict names (torch tensors or arrays)."""
 
-    def __init__(self, policy_sd=None, value_sd=None, device_id=0, max_batch=4096, precision=None):
+    def __init__(self, policy_sd=None, value_sd=None, device_id=0, max_batch=4096, precision=None, lib_path=None):
+        """lib_path: another build of the library (tests load the fault-injection build, _lib.HOOKS_LIB_PATH)."""
         if policy_sd is None and value_sd is None:
             raise TypeError("LeafEngine needs policy and/or value weights")
-        lib = L.load()
+        lib = L.load(lib_path)
         pw, vw, keep = self._weight_structs(policy_sd, value_sd)
         h = ctypes.c_void_p()
         rc = lib.bk_engine_create(ctypes.byref(pw) if pw is not None else None,
@@ -263,6 +264,40 @@ class LeafEngine:
         return out
 
     # -- misc ---------------------------------------------------------------------------------
+    def set_option(self, name, value):
+        """A diagnostic switch of this engine (bk_engine_set_option): 'coop', 'coop3', 'force_nb', 'no_split', 'no_direct',
+        'no_head_part', 'copy_threads', 'encode_overlap'.  The environment is read once, when the engine is created; a live
+        engine is changed here.  Results never depend on a switch."""
+        self._check(self._lib.bk_engine_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int(0)
+        self._check(self._lib.bk_engine_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """with engine.options(coop=0): ... -- switches set for the block, put back afterwards"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return scope()
+
+    def evaluator(self):
+        """This engine as the evaluator of the native step loop (bk_engine_evaluator -> selfplay.Evaluator struct)."""
+        from .selfplay import EvaluatorStruct
+        ev = EvaluatorStruct()
+        self._check(self._lib.bk_engine_evaluator(self._h, ctypes.byref(ev)))
+        return ev
+
     def set_profiling(self, on=True):
         self._check(self._lib.bk_engine_set_profiling(self._h, int(on)))
 

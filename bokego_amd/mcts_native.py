@@ -151,17 +151,10 @@ class NativeMCTS:
         self.noise_weight = kwargs.get("noise_weight", 0)
         # mcts.py:65-72
         self.value_net_weight = 1.0 if self.no_sim else (0.0 if not has_value else kwargs.get("value_net_weight", 0.5))
+        self._max_batch = kwargs.get("max_batch")
         ev = kwargs.get("evaluator")
         if ev is None:
-            if isinstance(policy_net, nnet.HipPolicyNet) and isinstance(value_net, nnet.HipValueNet):
-                ev = selfplay.EngineEvaluator(nnet.fuse(policy_net, value_net, kwargs.get("max_batch")))
-            elif isinstance(policy_net, nnet.HipPolicyNet) and value_net is None:
-                ev = selfplay.EngineEvaluator(policy_net.engine(), value=False)
-            else:  # any callables: policy(x)->logits, value(x)->[B,1]  (CPU tests use the oracle nets)
-                import torch
-                ev = selfplay.CallableEvaluator(lambda x: policy_net(torch.from_numpy(x)).numpy(),
-                                                None if value_net is None else
-                                                (lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1)))
+            ev = self._evaluator_from_nets()
         self.evaluator = ev
         # Evaluation ahead of expansion (bokego_tree.h, `speculate`): same search, fewer round trips, more rows per request.
         # It pays as long as the bigger request costs about the same: the f16x2 kernel runs <= 256 rows as one round of
@@ -184,7 +177,8 @@ class NativeMCTS:
             if self.branch_num == 0:
                 raise NotImplementedError("branch_num = 0 (no children at all) is not a search; use bokego_amd.mcts.MCTS to reproduce it")
             prm.branch_num = int(self.branch_num)
-        self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=kwargs.get("cap", 1024), threads=1)
+        self._cap = kwargs.get("cap", 1024)
+        self._pool = selfplay.GamePool([kwargs.get("seed", 0)], prm, cap=self._cap, threads=1)
         self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, "Q")
         self._has_value = has_value
         self.children = _ChildrenView(self)
@@ -196,6 +190,64 @@ class NativeMCTS:
         self._pump()
 
     # ---- plumbing ------------------------------------------------------------------------------------
+    def _evaluator_from_nets(self):
+        policy_net, value_net = self.policy_net, self.value_net
+        if isinstance(policy_net, nnet.HipPolicyNet) and isinstance(value_net, nnet.HipValueNet):
+            return selfplay.EngineEvaluator(nnet.fuse(policy_net, value_net, self._max_batch))
+        if isinstance(policy_net, nnet.HipPolicyNet) and value_net is None:
+            return selfplay.EngineEvaluator(policy_net.engine(), value=False)
+        # any callables: policy(x)->logits, value(x)->[B,1]  (CPU tests use the oracle nets)
+        import torch
+        return selfplay.CallableEvaluator(lambda x: policy_net(torch.from_numpy(x)).numpy(),
+                                          None if value_net is None else
+                                          (lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1)))
+
+    # ---- copies and pickles (mcts.py:81-108): the search state travels, the networks do not -----------------
+    _PLAIN = ("no_sim", "branch_num", "expand_thresh", "exploration_weight", "noise_weight", "value_net_weight", "komi",
+              "_spec_kw", "_spec_prec", "_has_value", "_max_batch", "_cap")
+
+    def _adopt(self, blob, cap):
+        """a fresh one-game pool holding the snapshot `blob` (its search parameters come with it)"""
+        self._pool = selfplay.GamePool([0], selfplay.search_params(rollouts=0), cap=cap, threads=1)
+        self._lib = self._pool._lib
+        self._pool.restore(0, blob)
+        self.N, self.V, self.Q = _TreeView(self, "N"), _TreeView(self, "V"), _TreeView(self, "Q")
+        self.children = _ChildrenView(self)
+
+    def __getstate__(self):
+        """MCTS.__getstate__ (mcts.py:93-96): everything but the nets -- here the native tree as a snapshot
+        (bk_pool_snapshot: nodes, edges, priors, N / V / Q, root, generator) and the keyword arguments."""
+        d = {k: getattr(self, k) for k in self._PLAIN}
+        d["snapshot"] = self._pool.snapshot(0)
+        return d
+
+    def __setstate__(self, state):
+        """MCTS.__setstate__ (mcts.py:97-108): the tree is back; `policy_net` / `value_net` are None and are set by the
+        caller (`tree.policy_net = ...; tree.value_net = ...`), the evaluator is rebuilt from them on first use."""
+        state = dict(state)
+        blob = state.pop("snapshot")
+        self.__dict__.update(state)
+        self.policy_net = self.value_net = self.evaluator = None
+        self._adopt(blob, self._cap)
+
+    def __deepcopy__(self, memo):
+        """MCTS.__deepcopy__ (mcts.py:81-90): an independent copy of the search state that shares the networks -- and here
+        the evaluator (the engine) -- with the original."""
+        new = self.__class__.__new__(self.__class__)
+        for k in self._PLAIN:
+            setattr(new, k, getattr(self, k))
+        new.policy_net, new.value_net, new.evaluator = self.policy_net, self.value_net, self.evaluator
+        new._adopt(self._pool.snapshot(0), self._cap)
+        return new
+
+    def _ready(self):
+        """an unpickled tree gets its evaluator from the nets the caller has put back (mcts.py:106-108); called before anything
+        is changed in the native tree, so that a tree without nets refuses the call and stays as it is"""
+        if self.evaluator is None:
+            if self.policy_net is None:
+                raise RuntimeError("this tree was unpickled without its networks: set tree.policy_net / tree.value_net first")
+            self.evaluator = self._evaluator_from_nets()
+
     def _engine_precision(self):
         return getattr(getattr(self.evaluator, "engine", None), "precision", None)
 
@@ -205,6 +257,7 @@ class NativeMCTS:
 
     def _pump(self):
         """Run the native search until it needs nothing more (every outstanding rollout done)."""
+        self._ready()
         prec = self._engine_precision()
         if prec != self._spec_prec:           # engine.set_precision() since the last call: the other kernel's defaults
             self._spec_prec = prec
@@ -276,6 +329,7 @@ class NativeMCTS:
         """n rollouts from the root (mcts.py:133-151).  analyze_dict: as in the reference, every descent longer than two
         nodes is stored under the root child it went through (child -> [child, ..., leaf]); the native search records the
         node ids, the dict receives position objects."""
+        self._ready()
         if analyze_dict is not None:
             self._lib.bk_pool_set_analyze(self._pool._h, 1)
         self._lib.bk_pool_add_rollouts(self._pool._h, 0, int(n))
@@ -317,6 +371,7 @@ class NativeMCTS:
         r = self.root
         if r._terminal:
             return r
+        self._ready()
         mv = self._lib.bk_pool_choose(self._pool._h, 0)
         if mv == go._NO_MOVE:
             # the root has no children -- no legal move at all, or (branch_num) none among the policy's top k: the reference's
@@ -362,6 +417,7 @@ class NativeMCTS:
 
     def play(self, move):
         """An outside move: the root's child for `move` (created if needed) becomes the root."""
+        self._ready()
         rc = self._lib.bk_pool_play(self._pool._h, 0, int(move))
         if rc:
             raise go.IllegalMove(self.root, rule_type=go._RULES.get(rc), sq_c=move)
@@ -369,6 +425,7 @@ class NativeMCTS:
 
     def set_root(self, node):
         """Any position; if it is one move away from the current root the subtree is kept."""
+        self._ready()
         r = self.root
         self.komi = getattr(node, "komi", self.komi)
         if node.turn == r.turn + 1 and node.last_move is not None:

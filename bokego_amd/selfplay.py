@@ -47,6 +47,25 @@ class GameInfo(ctypes.Structure):
                 ("root_V", ctypes.c_double)]
 
 
+class GameStats(ctypes.Structure):
+    _fields_ = [("root_visits", ctypes.c_uint64 * 81), ("sum_root_value", ctypes.c_double),
+                ("sum_abs_root_value", ctypes.c_double), ("n_root_values", ctypes.c_uint64)]
+
+
+_SUBMIT_FN = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+_WAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64)
+
+
+class EvaluatorStruct(ctypes.Structure):
+    """bk_evaluator (include/bokego_tree.h): what bk_pools_run calls to have a batch evaluated"""
+    _fields_ = [("ctx", ctypes.c_void_p), ("submit", _SUBMIT_FN), ("wait", _WAIT_FN)]
+
+
+class RunInfo(ctypes.Structure):
+    _fields_ = [("steps", ctypes.c_uint64), ("rows", ctypes.c_uint64), ("policy_rows", ctypes.c_uint64),
+                ("seconds", ctypes.c_double), ("wait_seconds", ctypes.c_double)]
+
+
 _VP = ctypes.c_void_p
 TREE_SYMBOLS = {
     "bk_search_params_default": (None, [ctypes.POINTER(SearchParams)]),
@@ -83,6 +102,11 @@ TREE_SYMBOLS = {
     "bk_pool_principal_variation": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int]),
     "bk_pool_set_analyze": (None, [_VP, ctypes.c_int]),
     "bk_pool_variation": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int]),
+    "bk_pool_game_stats": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(GameStats)]),
+    "bk_pool_snapshot": (ctypes.c_long, [_VP, ctypes.c_int, _VP, ctypes.c_long]),
+    "bk_pool_restore": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_long]),
+    "bk_pools_run": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(EvaluatorStruct), ctypes.c_int, ctypes.POINTER(RunInfo)]),
+    "bk_normalise_rows": (None, [_VP, ctypes.c_int]),
 }
 _tree_ready = False
 
@@ -144,12 +168,39 @@ class GamePool:
         self._feats = self._recs = None   # allocated by the collect flavour in use
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):         # (a constructor that failed before the handle existed has nothing to close)
             self._lib.bk_pool_destroy(self._h)
             self._h = None
 
     def __del__(self):
         self.close()
+
+    def game_stats(self, g):
+        """Visit / value statistics of the moves game g has chosen (bk_pool_game_stats): (root_visits[81] uint64 array,
+        sum_root_value, sum_abs_root_value, n_root_values)."""
+        st = GameStats()
+        if self._lib.bk_pool_game_stats(self._h, int(g), ctypes.byref(st)):
+            raise IndexError(g)
+        return np.frombuffer(st.root_visits, np.uint64).copy(), st.sum_root_value, st.sum_abs_root_value, int(st.n_root_values)
+
+    def snapshot(self, g=0):
+        """The search state of game g as bytes (bk_pool_snapshot: tree, statistics, priors, moves, generator; no nets).
+        Only between a deliver and the next collect."""
+        n = self._lib.bk_pool_snapshot(self._h, int(g), None, 0)
+        if n < 0:
+            raise RuntimeError("bk_pool_snapshot: the game has a request out" if n == -2 else f"bk_pool_snapshot failed ({n})")
+        buf = ctypes.create_string_buffer(n)
+        if self._lib.bk_pool_snapshot(self._h, int(g), buf, n) != n:
+            raise RuntimeError("bk_pool_snapshot failed")
+        return buf.raw
+
+    def restore(self, g, blob):
+        """Replace game g by a snapshot (bk_pool_restore); ValueError if the bytes are not one of this build's."""
+        rc = self._lib.bk_pool_restore(self._h, int(g), blob, len(blob))
+        if rc == -3:
+            raise ValueError("not a snapshot taken by this build of libbkgo.so")
+        if rc:
+            raise RuntimeError("bk_pool_restore: the game has a request out" if rc == -2 else f"bk_pool_restore failed ({rc})")
 
     def set_task_cap(self, tasks):
         """Soft limit of a batch in network tasks (bk_pool_set_task_cap); 0: none."""
@@ -216,10 +267,21 @@ class GamePool:
 
 
 def normalise_like_categorical(probs):
-    """torch's Categorical(probs) divides by the row sum (reference nnet.py:274)."""
+    """torch's Categorical(probs) divides by the row sum (reference nnet.py:274): the one-tree search (NativeMCTS, whose
+    traces are compared with the reference's) normalises its priors with torch itself."""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(probs, dtype=np.float32))
     return (t / t.sum(-1, keepdim=True)).numpy()
+
+
+def normalise_rows(probs):
+    """The same division with the row sum taken left to right in fp32 (bk_normalise_rows): what the lock-step pools use --
+    in the Python step loop, in the native one (bk_pools_run) and in examples/bk_selfplay.c -- so that the three play the
+    same games bit for bit (torch's sum is vectorised, its order depends on the CPU it runs on)."""
+    a = np.array(probs, dtype=np.float32, order="C", copy=True)
+    if a.size:
+        treelib().bk_normalise_rows(a.ctypes.data, int(a.shape[0]))
+    return a
 
 
 class EngineEvaluator:
@@ -244,10 +306,10 @@ class EngineEvaluator:
             return self.engine.submit_positions(feats, logits=False, probs=n_policy > 0, value=self.value, n_policy=n_policy), (n_policy, len(feats))
         return self.engine.submit(feats, logits=False, probs=n_policy > 0, value=self.value, n_policy=n_policy), (n_policy, len(feats))
 
-    def finish(self, handle):
+    def finish(self, handle, normalise=normalise_like_categorical):
         t, (npol, rows) = handle
         out = self.engine.wait(t)
-        probs = normalise_like_categorical(out["probs"]) if npol else np.zeros((0, 81), np.float32)
+        probs = normalise(out["probs"]) if npol else np.zeros((0, 81), np.float32)
         return probs, out["value"] if self.value else np.zeros(rows, np.float32)
 
     def __call__(self, feats, n_policy):
@@ -264,7 +326,7 @@ class CallableEvaluator:
     def submit(self, feats, n_policy):
         return feats.copy(), n_policy
 
-    def finish(self, handle):
+    def finish(self, handle, normalise=normalise_like_categorical):
         import torch
         feats, npol = handle
         self.positions += len(feats)
@@ -272,7 +334,7 @@ class CallableEvaluator:
         x = feats.astype(np.float32)
         if npol:
             lg = torch.from_numpy(np.asarray(self.policy_fn(x[:npol]), dtype=np.float32))
-            probs = normalise_like_categorical(torch.softmax(lg, dim=1).numpy())
+            probs = normalise(torch.softmax(lg, dim=1).numpy())
         else:
             probs = np.zeros((0, 81), np.float32)
         if self.value_fn is None:          # no value net (simulation mode, mcts.py:68-69): zeros nobody reads
@@ -296,16 +358,68 @@ class RecordEvaluator(CallableEvaluator):
         return feats, n_policy
 
 
+def callback_evaluator(evaluator):
+    """Any Python evaluator (submit / finish) as a bk_evaluator for the native step loop: the CPU tests run bk_pools_run on
+    the oracle nets this way.  The batch is evaluated inside submit(); keep the returned struct alive while it is in use."""
+    state = {"ticket": 0, "error": None}
+
+    def submit(_ctx, recs, B, n_policy, probs, values):
+        try:
+            r = np.ctypeslib.as_array((ctypes.c_uint8 * (B * 192)).from_address(recs)).reshape(B, 192)
+            if not getattr(evaluator, "wants_positions", False):
+                raise TypeError("the native step loop hands over position records: the evaluator must take them (RecordEvaluator)")
+            p, v = evaluator.finish(evaluator.submit(r, n_policy), normalise=lambda x: x)
+            if n_policy:
+                np.ctypeslib.as_array((ctypes.c_float * (n_policy * 81)).from_address(probs))[:] = np.asarray(p, np.float32).reshape(-1)
+            np.ctypeslib.as_array((ctypes.c_float * B).from_address(values))[:] = np.asarray(v, np.float32).reshape(-1)
+            state["ticket"] += 1
+            return state["ticket"]
+        except BaseException as exc:          # an exception must not unwind through the C loop
+            state["error"] = exc
+            return -2
+
+    ev = EvaluatorStruct(None, _SUBMIT_FN(submit), _WAIT_FN(lambda _ctx, _t: 0))
+    ev._state = state
+    return ev
+
+
+def run_pools_native(pools, evaluator, cap=None):
+    """run_pools with the step loop in C (bk_pools_run): no interpreter between two steps.  evaluator: an EngineEvaluator on
+    position records (the engine's own bk_evaluator is used), or any evaluator of records (through callbacks).  Returns the
+    number of steps; evaluator.positions / .batches are kept up to date."""
+    lib = treelib()
+    eng = getattr(evaluator, "engine", None)
+    if eng is not None and getattr(evaluator, "wants_positions", False) and getattr(evaluator, "value", True) == eng.has_value:
+        ev = eng.evaluator()
+    else:
+        ev = callback_evaluator(evaluator)
+    handles = (ctypes.c_void_p * len(pools))(*[p._h for p in pools])
+    info = RunInfo()
+    cap = int(cap or min(p.cap for p in pools))
+    rc = lib.bk_pools_run(handles, len(pools), ctypes.byref(ev), cap, ctypes.byref(info))
+    err = getattr(ev, "_state", {}).get("error")
+    if err is not None:
+        raise err
+    if rc:
+        msg = eng._lib.bk_last_error(eng._h).decode() if eng is not None else ""
+        raise RuntimeError(f"bk_pools_run failed ({rc}) {msg}")
+    if eng is not None and hasattr(evaluator, "positions"):
+        evaluator.positions += int(info.rows)
+        evaluator.batches += int(info.steps)
+    run_pools_native.last_info = {f: getattr(info, f) for f, _ in RunInfo._fields_}
+    return int(info.steps)
+
+
 def run_pools(pools, evaluator, progress=None):
     """Drive one or two pools to completion.  With two pools the host advances one while the
-    evaluator (GPU) works on the other's batch."""
+    evaluator (GPU) works on the other's batch.  (The step loop in Python; run_pools_native is the same loop in C.)"""
     inflight = [None] * len(pools)
     live = [True] * len(pools)
     steps = 0
     while any(live) or any(h is not None for h in inflight):
         for i, pool in enumerate(pools):
             if inflight[i] is not None:
-                probs, values = evaluator.finish(inflight[i])
+                probs, values = evaluator.finish(inflight[i], normalise=normalise_rows)
                 pool.deliver(probs, values)
                 inflight[i] = None
             if live[i]:
@@ -320,16 +434,28 @@ def run_pools(pools, evaluator, progress=None):
     return steps
 
 
-STATS_FIELDS = ["games", "black_wins", "white_wins", "plies", "sum_score", "value_evals", "policy_evals", "requests"]
-STATS_LEN = len(STATS_FIELDS) + 81  # + histogram of first moves
+# The vector the generation's one all-reduce sums (north_star: "all-reduce visit/value statistics at the end of a generation";
+# SURVEY 8e).  Scalars, then two histograms over the 81 points:
+#   sum_root_value / sum_abs_root_value / n_root_values   over every ply of every game: V[root] / N[root] when the move was
+#       chosen (2 winrate - 1 from the side to move, mcts.py:159-170), its magnitude, and the number of plies
+#   first_move_hist[81]      games by their first move
+#   root_visit_hist[81]      sum over every ply of every game of the root's children's visit counts, by move (mcts.py:122-128)
+# Every entry is an integer or a multiple of 2^-32 far below 2^53 in magnitude: the sums are exact in float64, so the reduced
+# vector does not depend on the order of addition (world size, ring order).  173 doubles = 1,384 bytes.
+STATS_FIELDS = ["games", "black_wins", "white_wins", "plies", "sum_score", "value_evals", "policy_evals", "requests",
+                "sum_root_value", "sum_abs_root_value", "n_root_values"]
+STATS_HISTS = ["first_move_hist", "root_visit_hist"]
+STATS_LEN = len(STATS_FIELDS) + 81 * len(STATS_HISTS)
 
 
 def pool_stats(pools):
     s = np.zeros(STATS_LEN, np.float64)
+    first, visits = len(STATS_FIELDS), len(STATS_FIELDS) + 81
     for p in pools:
         for g in range(p.n):
             gi = p.info(g)
             mv = p.moves(g)
+            rv, sv, sa, nv = p.game_stats(g)
             s[0] += 1
             s[1] += gi["score"] > 0
             s[2] += gi["score"] <= 0
@@ -338,9 +464,24 @@ def pool_stats(pools):
             s[5] += gi["n_value_evals"]
             s[6] += gi["n_policy_evals"]
             s[7] += gi["n_requests"]
+            s[8] += sv
+            s[9] += sa
+            s[10] += nv
             if mv and mv[0] >= 0:
-                s[len(STATS_FIELDS) + mv[0]] += 1
+                s[first + mv[0]] += 1
+            s[visits:visits + 81] += rv.astype(np.float64)
     return s
+
+
+def named_stats(total):
+    """The reduced vector as a dict: the scalars by name, the two histograms as integer lists."""
+    named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}
+    for j, h in enumerate(STATS_HISTS):
+        at = len(STATS_FIELDS) + 81 * j
+        named[h] = [int(round(x)) for x in total[at:at + 81]]
+    named["mean_root_value"] = named["sum_root_value"] / named["n_root_values"] if named["n_root_values"] else 0.0
+    named["mean_abs_root_value"] = named["sum_abs_root_value"] / named["n_root_values"] if named["n_root_values"] else 0.0
+    return named
 
 
 def all_reduce_stats(stats, device=None, native_comm=None):
@@ -430,6 +571,9 @@ def default_eager_top(precision, n_games_here):
 DEDUP = {"f32": True, "f16x2": False}
 
 
+NATIVE_LOOP = os.environ.get("BK_NATIVE_LOOP", "1") != "0"     # the pools' step loop in C (bk_pools_run); 0: in Python
+
+
 def shard_game_ids(n_games, rank, world):
     return [g for g in range(n_games) if g % world == rank]
 
@@ -437,12 +581,14 @@ def shard_game_ids(n_games, rank, world):
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
               reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None,
-              dedup=None):
+              dedup=None, native_loop=None):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
     a later job) with the same games coming out; the reference's launcher can only raise when a worker fails
-    (bin/selfplay.py:196-199).  The statistics returned are those of the games played here."""
+    (bin/selfplay.py:196-199).  The statistics returned are those of the games played here.
+    native_loop: the step loop in C (run_pools_native) instead of in Python (run_pools); the same games either way.
+    Default: C whenever the evaluator takes position records and nobody asked for per-step progress calls."""
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
     if eager_top is None:
@@ -480,8 +626,13 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     for pool in pools:
         pool.set_task_cap(task_cap)
         pool.set_dedup(dedup and getattr(evaluator, "wants_positions", False))
+    if native_loop is None:
+        native_loop = NATIVE_LOOP and progress is None and getattr(evaluator, "wants_positions", False)
     t0 = time.perf_counter()
-    steps = run_pools(pools, evaluator, progress)
+    if native_loop and pools:
+        steps = run_pools_native(pools, evaluator, cap=cap)
+    else:
+        steps = run_pools(pools, evaluator, progress)
     dt = time.perf_counter() - t0
     games, visits = {}, {}
     for part, pool in zip(parts, pools):
@@ -494,10 +645,9 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     total, t_reduce = all_reduce_stats(local, reduce_device, native_comm)
     for p in pools:
         p.close()
-    named = {k: float(total[i]) for i, k in enumerate(STATS_FIELDS)}
-    named["first_move_hist"] = total[len(STATS_FIELDS):].astype(int).tolist()
-    return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local,
-             "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
+    named = named_stats(total)
+    return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local, "native_loop": bool(native_loop),
+             "n_pools": n_pools, "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
 
 
 # ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------

@@ -1,16 +1,17 @@
 /*
  * bk_selfplay.c -- BASELINE config 4 without Python: a generation of self-play games driven from C through the
  * four C ABIs (include/bokego_amd.h engine, bokego_go.h records, bokego_tree.h game pools, bokego_comm.h
- * all-reduce).  The same loop as bokego_amd/selfplay.py:run_pools -- three lock-step pools rotate through one
- * engine, so the host advances one pool's trees while the GPU evaluates the others' leaves.
+ * all-reduce).  The step loop is bk_pools_run (include/bokego_tree.h) with the engine's own evaluator
+ * (bk_engine_evaluator): lock-step pools rotate through one engine, so the host advances one pool's trees while the
+ * GPU evaluates the others' leaves -- what bokego_amd/selfplay.py does by default.
  *
  *   make -C bokego_amd/csrc examples
  *   ./examples/bk_selfplay tests/golden/policy_19.bkw tests/golden/value_synth.bkw [games=512] [rollouts=400]
  *   multi-GPU (one process per GPU): BK_RANK=r BK_WORLD=n BK_COMM_ID_FILE=/shared/path ./examples/bk_selfplay ...
  *
- * Games are assigned gid % world and seeded by 20260 + gid, as in the Python driver.  (The priors are
- * normalised here with a plain left-to-right fp32 sum, torch's Categorical uses a vectorised one, so games can
- * differ from the Python driver's in the last bit of a prior; each driver is deterministic.)
+ * Games are assigned gid % world and seeded by 20260 + gid, as in the Python driver, and the priors are normalised
+ * by the same bk_normalise_rows: the two drivers play the same games move for move (the checksum below is over every
+ * move of every game; tests/test_gpu_comm.py compares the statistics with the Python driver's).
  */
 #include <time.h>
 #include <unistd.h>
@@ -25,10 +26,7 @@
 
 typedef struct {
     bk_pool *pool;
-    bk_pos *recs;
-    float *probs, *values;
-    int64_t ticket;
-    int n, npol, live, n_games;
+    int n_games;
 } slot_t;
 
 static double now(void) {
@@ -102,47 +100,23 @@ int main(int argc, char **argv) {
             }
         }
         s[i].n_games = k;
-        s[i].recs = malloc(sizeof(bk_pos) * CAP);
-        s[i].probs = malloc(sizeof(float) * 81 * CAP);
-        s[i].values = malloc(sizeof(float) * CAP);
-        s[i].ticket = 0;
-        s[i].live = 1;
         free(ps);
     }
 
     const double t0 = now();
-    long steps = 0, positions = 0;
-    for (int busy = 1; busy;) {
-        busy = 0;
-        for (int i = 0; i < npools; ++i) {
-            slot_t *p = &s[i];
-            if (p->ticket) {
-                if (bk_wait(e, p->ticket)) { fprintf(stderr, "bk_wait: %s\n", bk_last_error(e)); return 1; }
-                for (int r = 0; r < p->npol; ++r) {          /* Categorical(probs) re-normalises (nnet.py:274) */
-                    float sum = 0.f, *row = p->probs + 81 * r;
-                    for (int k = 0; k < 81; ++k) sum += row[k];
-                    for (int k = 0; k < 81; ++k) row[k] /= sum;
-                }
-                bk_pool_deliver(p->pool, p->probs, p->values);
-                p->ticket = 0;
-            }
-            if (p->live) {
-                p->n = bk_pool_collect_pos(p->pool, p->recs, CAP, &p->npol);
-                if (p->n == 0) { p->live = 0; continue; }
-                p->ticket = bk_submit_positions(e, p->recs, p->n, p->npol, (p->npol ? BK_WANT_PROBS : 0) | BK_WANT_VALUE, NULL,
-                                                p->probs, p->values);
-                if (p->ticket < 0) { fprintf(stderr, "bk_submit_positions: %s\n", bk_last_error(e)); return 1; }
-                ++steps;
-                positions += p->n;
-                busy = 1;
-            }
-            busy |= p->ticket != 0;
-        }
-    }
+    bk_evaluator ev;
+    bk_run_info info;
+    bk_pool *pools[NPOOLS];
+    for (int i = 0; i < npools; ++i) pools[i] = s[i].pool;
+    if (bk_engine_evaluator(e, &ev)) { fprintf(stderr, "bk_engine_evaluator: %s\n", bk_last_error(e)); return 1; }
+    if (bk_pools_run(pools, npools, &ev, CAP, &info)) { fprintf(stderr, "bk_pools_run: %s\n", bk_last_error(e)); return 1; }
+    const long steps = (long)info.steps, positions = (long)info.rows;
     const double secs = now() - t0;
 
-    /* statistics vector, as bokego_amd/selfplay.py:pool_stats: 8 scalars + first-move histogram */
-    double st[8 + 81];
+    /* statistics vector, as bokego_amd/selfplay.py:pool_stats: 11 scalars (the last three: sum / sum of magnitudes / count of
+     * the root's mean backed-up value at every move) + first-move histogram + root-child visit histogram */
+    enum { NSCAL = 11, NST = NSCAL + 2 * 81 };
+    double st[NST];
     memset(st, 0, sizeof st);
     unsigned long long check = 1469598103934665603ull;    /* FNV-1a over every move of every game (determinism check) */
     for (int i = 0; i < npools; ++i)
@@ -153,7 +127,11 @@ int main(int argc, char **argv) {
             const int nm = bk_pool_game_moves(s[i].pool, g, mv, 128);
             st[0] += 1; st[1] += gi.score > 0; st[2] += gi.score <= 0; st[3] += gi.n_moves; st[4] += gi.score;
             st[5] += (double)gi.n_value_evals; st[6] += (double)gi.n_policy_evals; st[7] += (double)gi.n_requests;
-            if (nm > 0 && mv[0] >= 0) st[8 + mv[0]] += 1;
+            bk_game_stats gs;
+            bk_pool_game_stats(s[i].pool, g, &gs);
+            st[8] += gs.sum_root_value; st[9] += gs.sum_abs_root_value; st[10] += (double)gs.n_root_values;
+            if (nm > 0 && mv[0] >= 0) st[NSCAL + mv[0]] += 1;
+            for (int k = 0; k < 81; ++k) st[NSCAL + 81 + k] += (double)gs.root_visits[k];
             for (int k = 0; k < nm; ++k) check = (check ^ (unsigned short)mv[k]) * 1099511628211ull;
         }
     double reduce_ms = 0;
@@ -187,7 +165,7 @@ int main(int argc, char **argv) {
         if (bk_comm_init(rank, world, id, device, &c)) { fprintf(stderr, "bk_comm_init: %s\n", bk_comm_last_error()); return 1; }
         if (rank == 0) remove(idf);   /* every rank has joined: the next run must not find this id */
         const double t1 = now();
-        if (bk_comm_allreduce_sum_f64(c, st, 8 + 81)) { fprintf(stderr, "allreduce: %s\n", bk_comm_last_error()); return 1; }
+        if (bk_comm_allreduce_sum_f64(c, st, NST)) { fprintf(stderr, "allreduce: %s\n", bk_comm_last_error()); return 1; }
         reduce_ms = (now() - t1) * 1e3;
         bk_comm_destroy(c);
     }
@@ -197,11 +175,15 @@ int main(int argc, char **argv) {
         bk_pool_phase_seconds(s[i].pool, t);
         for (int k = 0; k < 3; ++k) host[k] += t[k];
     }
+    double visit_sum = 0;
+    for (int k = 0; k < 81; ++k) visit_sum += st[NSCAL + 81 + k];
     if (rank == 0)
         printf("{\"games\": %.0f, \"local_games\": %d, \"seconds\": %.4f, \"local_games_per_min\": %.0f, \"steps\": %ld, \"mean_batch\": %.0f, "
                "\"plies\": %.0f, \"black_wins\": %.0f, \"value_evals\": %.0f, \"policy_evals\": %.0f, \"allreduce_ms\": %.3f, "
+               "\"sum_root_value\": %.9f, \"sum_abs_root_value\": %.9f, \"n_root_values\": %.0f, \"root_visit_hist_sum\": %.0f, \"wait_s\": %.3f, "
                "\"host_advance_s\": %.3f, \"host_emit_s\": %.3f, \"host_deliver_s\": %.3f, \"moves_checksum\": \"%016llx\"}\n",
                st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms,
+               st[8], st[9], st[10], visit_sum, info.wait_seconds,
                host[0], host[1], host[2], check);
     for (int i = 0; i < npools; ++i) bk_pool_destroy(s[i].pool);
     bk_engine_destroy(e);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BK_ABI_VERSION 6
+#define BK_ABI_VERSION 7
 
 typedef enum bk_status {
     BK_OK = 0,
@@ -149,11 +149,11 @@ int bk_eval_device(bk_engine *e, const void *d_feats, int feats_dtype, int B, in
  * kernel of another and the D2H copy of a third run concurrently.
  * How a request travels (results never depend on it; every variant is bit-identical):
  *   - at most 256 positions, fp32 engine: no copies at all -- the feature encoder (bk_submit_positions) reads the records from
- *     the pinned slot, the leaf kernel writes its flag word and outputs into the pinned output block (BK_NO_DIRECT=1: copies);
+ *     the pinned slot, the leaf kernel writes its flag word and outputs into the pinned output block (option no_direct: copies);
  *     up to 128 network tasks run as the cooperative launch (2..12 CUs per board);
  *   - larger requests: H2D, kernels and D2H on three event-chained streams; host planes of >= 4 MiB are staged by a small
  *     pool of copy threads whose slices are sent as they land, and from 16 MiB the first 768 positions are launched as soon as
- *     THEIR planes have arrived, running while the rest is copied (BK_NO_HEAD_PART=1, BK_COPY_THREADS=0: off).
+ *     THEIR planes have arrived, running while the rest is copied (options no_head_part = 1, copy_threads = 0: off).
  */
 #define BK_MAX_INFLIGHT 4
 int64_t bk_submit(bk_engine *e, const void *feats, int feats_dtype, int B, int want, float *logits, float *probs,
@@ -206,6 +206,29 @@ int bk_engine_set_precision(bk_engine *e, int precision);
 int bk_engine_get_precision(bk_engine *e);
 
 int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every kernel launch */
+
+/*
+ * Diagnostic switches of one engine (ABI 7).  Their defaults come from the environment, which is read ONCE, inside
+ * bk_engine_create (BK_PRECISION, BK_FORCE_NB, BK_NO_SPLIT, BK_COOP, BK_COOP3, BK_NO_DIRECT, BK_NO_HEAD_PART, BK_COPY_THREADS,
+ * BK_ENCODE_OVERLAP, BK_ROCTX); no request ever looks at the environment, and a live engine is changed through this call
+ * only.  Results never depend on any of them (every launch form is bit-identical); they exist so that tests and probes can
+ * force each form.  Names: "force_nb" (0 | 1..3 boards per workgroup), "no_split", "coop" (-1 by task count | 0 off | 2, 3,
+ * 4, 6, 8, 12 CUs per board), "coop3" (-1 | 0 | 2 | 4), "no_direct", "no_head_part", "copy_threads", "encode_overlap".
+ * Unknown name: BK_ERR_ARG.  Builds with -DBK_TEST_HOOKS (bk_has_test_hooks() == 1; never shipped as libbokego_amd.so) add
+ * "coop_fault" and "fault_submit" (fault injection for tests/test_gpu_hooks.py).
+ */
+int bk_engine_set_option(bk_engine *e, const char *name, int value);
+int bk_engine_get_option(bk_engine *e, const char *name, int *value);
+int bk_has_test_hooks(void);
+
+/*
+ * The engine as the evaluator of the native step loop (include/bokego_tree.h: bk_pools_run drives lock-step game pools
+ * through two callbacks): fills *out with { ctx = e, submit = bk_submit_positions(PROBS for the policy rows | VALUE), wait =
+ * bk_wait }.  Replaces: the per-position calls of Go_MCTS.dist / .value (mcts.py:371-403) for every tree of a self-play
+ * worker (bin/selfplay.py:177-199), with no interpreter between two batches.  `out` must not outlive the engine.
+ */
+struct bk_evaluator;
+int bk_engine_evaluator(bk_engine *e, struct bk_evaluator *out);
 int bk_stats(bk_engine *e, bk_stats_t *out);
 int bk_engine_max_batch(bk_engine *e);
 

@@ -5,8 +5,11 @@
  * The reference has no collective: its workers append to a multiprocessing Manager().list()
  * (bin/selfplay.py:179-180,201-204) and the parent sums.  Here every rank (one process per GPU) plays its
  * shard of the games (game id % world) with no communication, then ONE all-reduce(sum) of a short fp64
- * vector [games, black wins, white wins, plies, sum of scores, value evals, policy evals, requests,
- * first-move histogram[81]] gives every rank the generation's totals.  The Python host uses
+ * vector -- 173 values, 1,384 bytes: [games, black wins, white wins, plies, sum of scores, value evals, policy evals,
+ * requests, sum / sum of magnitudes / count of the root's mean backed-up value at every move, first-move histogram[81],
+ * histogram of root-child visit counts over every move[81]] (bokego_amd/selfplay.py:STATS_FIELDS; the per-game figures come
+ * from bk_pool_game_stats, include/bokego_tree.h; every entry is an integer or a multiple of 2^-32, so the sums are exact
+ * and independent of the reduction order) -- gives every rank the generation's visit / value statistics.  The Python host uses
  * torch.distributed (backend "nccl" = the same RCCL) for this; libbkcomm.so is the same step for hosts
  * without Python/torch.
  *

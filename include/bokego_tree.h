@@ -140,6 +140,20 @@ int bk_team_selftest_concurrent(int threads, int timeout_ms);
 int bk_pool_n_games(const bk_pool *p);
 int bk_pool_n_done(const bk_pool *p);
 int bk_pool_game_info(const bk_pool *p, int g, bk_game_info *out);
+/* Visit / value statistics of the moves game g has chosen so far -- what the end-of-generation all-reduce sums over all games
+ * (north_star: "all-reduce visit/value statistics at the end of a generation"; the reference's workers append their results to a
+ * Manager().list(), bin/selfplay.py:179-180,201-204):
+ *   root_visits[m]      sum over the plies played of N[child reached by move m] of the root at the moment the ply was chosen
+ *                       (MCTS.choose reads the same counts, mcts.py:122-128)
+ *   sum_root_value      sum over those plies of V[root] / N[root] (= 2 MCTS.winrate() - 1, mcts.py:159-170: the side to move's view)
+ *   sum_abs_root_value  ... of its magnitude;  n_root_values: the number of plies in the two sums
+ * The two sums are kept in 2^-32 fixed point, so totals over games are exact and do not depend on the order of addition. */
+typedef struct bk_game_stats {
+    uint64_t root_visits[81];
+    double sum_root_value, sum_abs_root_value;
+    uint64_t n_root_values;
+} bk_game_stats;
+int bk_pool_game_stats(const bk_pool *p, int g, bk_game_stats *out);
 int bk_pool_game_moves(const bk_pool *p, int g, int16_t *out, int cap);
 /* visit counts of the root's children when ply `ply` was chosen (needs record_visits); returns their number */
 int bk_pool_game_visits(const bk_pool *p, int g, int ply, int16_t *moves, int32_t *N);
@@ -197,6 +211,47 @@ int bk_pool_node_prior(const bk_pool *p, int g, int id, double *prior);
 int bk_pool_principal_variation(const bk_pool *p, int g, int16_t *moves, int cap);
 void bk_pool_set_analyze(bk_pool *p, int on);
 int bk_pool_variation(const bk_pool *p, int g, int move, int32_t *ids, int cap);
+
+/*
+ * Snapshot / restore of one game's search state (replaces: MCTS.__getstate__ / __setstate__ / __deepcopy__, mcts.py:81-108, and
+ * Go_MCTS.__getstate__ / __setstate__, mcts.py:281-292 -- the reference pickles a tree without its nets and deep-copies one that
+ * shares them): nodes, edges, priors, N / V / Q, root, moves played, visit records, counters, the game's generator state and
+ * its search parameters; the networks are not part of it.  A restored game continues rollout for rollout as the original would.
+ *   bk_pool_snapshot   returns the snapshot's size in bytes; the bytes are written when buf != NULL and cap is large enough
+ *                      (call with NULL first).  -1: bad argument; -2: the game has a request out (snapshots are taken between a
+ *                      deliver and the next collect -- for a manually driven game: whenever the caller holds it)
+ *   bk_pool_restore    replaces game g of ANY pool by the snapshot (its search parameters come with it).  0, -1 bad argument,
+ *                      -2 game g has a request out, -3 not a snapshot of this build (the game is left as it was)
+ * The format is private to one build of the library on one host architecture (it carries its structure sizes).
+ */
+long bk_pool_snapshot(const bk_pool *p, int g, void *buf, long cap);
+int bk_pool_restore(bk_pool *p, int g, const void *buf, long len);
+
+/*
+ * The whole step loop in C: what bokego_amd/selfplay.py:run_pools and examples/bk_selfplay.c do -- for every pool in turn: wait
+ * for its batch, re-normalise the priors (bk_normalise_rows), deliver, collect the next batch (position records), submit -- until
+ * every game of every pool is over; several pools rotate so that the host advances one while the evaluator works on the
+ * others' batches.  Between two steps there is no interpreter: a 64-game pool's step is a 100-170 us kernel, and 130 us of
+ * Python per step were what kept three small pools from overlapping (profiles/r04_pools_probe.txt).
+ * The evaluator is two callbacks: submit() starts the evaluation of B records (the first n_policy need policy + value, the rest
+ * the value only) and returns a ticket > 0 (or a negative error); probs[n_policy][81] (softmax outputs, not yet re-normalised)
+ * and values[B] must be filled in when wait(ticket) returns 0.  bk_engine_evaluator() (include/bokego_amd.h) fills one in for
+ * a HIP engine: bk_submit_positions / bk_wait.
+ * Returns 0, -1 for bad arguments, or the evaluator's error code (outstanding tickets are waited for first; the pools are
+ * then in the middle of a step and cannot be driven on).
+ */
+typedef struct bk_evaluator {
+    void *ctx;
+    int64_t (*submit)(void *ctx, const bk_pos *recs, int B, int n_policy, float *probs, float *values);
+    int (*wait)(void *ctx, int64_t ticket);
+} bk_evaluator;
+typedef struct bk_run_info {
+    uint64_t steps, rows, policy_rows;   /* batches submitted, rows in them, of which policy rows */
+    double seconds, wait_seconds;        /* wall time of the call; of which blocked in wait()      */
+} bk_run_info;
+int bk_pools_run(bk_pool *const *pools, int n_pools, const bk_evaluator *ev, int cap, bk_run_info *out);
+/* p / sum(p) per row of 81, as torch's Categorical(probs) does (nnet.py:274); the sum is taken left to right in fp32 */
+void bk_normalise_rows(float *probs, int n_rows);
 
 #ifdef __cplusplus
 }

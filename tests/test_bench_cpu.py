@@ -175,12 +175,13 @@ def test_counter_rows_fold_into_per_step_values():
     tot = {}
     assert bench.fold_counter_rows(rows(head, 1310720, 8, "FETCH_SIZE", 49000, 7_500_000) + rows(tail, 131072, 8, "FETCH_SIZE", 37000, 530_000)
                                    + rows(head, 91648, 1, "FETCH_SIZE", 9999, 800_000), tot)
-    assert tot == {"FETCH_SIZE": 49000.5 + 37000.5}
+    assert tot == {"FETCH_SIZE": 49000.5 + 37000.5, "_ns_FETCH_SIZE": 8_030_000.0}     # + the kernels' durations in this counter's pass
     assert bench.fold_counter_rows(rows(head, 1310720, 8, "GRBM_GUI_ACTIVE", 1.43e8, 7_500_000) + rows(tail, 131072, 8, "GRBM_GUI_ACTIVE", 1.0e7, 530_000), tot)
     assert tot["_ns"] == 8_030_000 and abs(tot["GRBM_GUI_ACTIVE"] - (1.43e8 + 1.0e7 + 1)) < 1e-3
     three = [r for c, v in (("SQ_WAVES", 20480), ("SQ_INSTS_VALU_MFMA_MOPS_F32", 2.1768e9), ("SQ_VALU_MFMA_BUSY_CYCLES", 1.74e10))
              for r in rows(head, 1310720, 4, c, v, 7_500_000)]
     assert bench.fold_counter_rows(three, tot) and abs(tot["SQ_WAVES"] - 20480.5) < 1e-9 and "SQ_VALU_MFMA_BUSY_CYCLES" in tot
+    assert tot["_ns_SQ_VALU_MFMA_BUSY_CYCLES"] == 7_500_000        # the child's kernel time under the MFMA-counter pass
     assert not bench.fold_counter_rows([], {})
     assert bench.under_profiler() is False
     from bokego_amd import _lib

@@ -88,5 +88,15 @@ def test_bench_starts_its_own_ranks():
     sp = d["selfplay"]
     assert sp["f32"]["games"] == 32 and sp["games_per_min"] > 0 and sp["stats_allreduce_ms"] > 0
     assert sp["f32"]["first_move_hist_sum"] == 32
+    # visit / value statistics in the reduced vector, what each rank needed, and a WEAK leg beside the strong one
+    f = sp["f32"]
+    assert f["n_root_values"] == f["plies"] and f["root_visit_hist_sum"] > 380 * f["plies"] and 0 < f["mean_abs_root_value"] < 1
+    assert len(f["per_rank_seconds"]) == 2 and f["per_rank_seconds_min"] <= f["per_rank_seconds_max"] == f["seconds"]
+    assert f["games_per_rank"] == 16 and len(f["stats_allreduce_ms_per_rank"]) == 2 and f["native_loop"]
+    w = sp["weak"]
+    assert w["games"] == 64 and w["games_per_rank"] == 32 and w["first_move_hist_sum"] == 64 and len(w["per_rank_seconds"]) == 2
+    assert 0 < sp["strong_scaling_efficiency_vs_own_weak_leg"] < 1.5 and 0 < sp["weak_scaling_per_rank_seconds_min_over_max"] <= 1
+    if r["pmc_file_fallback"] is None:       # the counter child's own kernel time: the factors multiply to the fraction AT that time
+        assert abs(r["frac_from_pmc_factors"] - r["frac_at_pmc_kernel_ms"]) < 0.02 * r["frac_at_pmc_kernel_ms"]
     B = d["config"]["batch_per_gpu"]
     assert abs(d["value"] - 2 * B * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

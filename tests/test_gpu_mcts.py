@@ -183,6 +183,39 @@ def test_config3_whole_game_matches_reference_on_both_trees(sds):
                        "identical_to_reference": True}, f)
 
 
+def test_native_tree_snapshot_continues_the_reference_trace(sds):
+    """NativeMCTS -- the tree the default launcher runs -- pickles and deep-copies like the reference's MCTS
+    (mcts.py:81-108: the nets do not travel; a deep copy shares them).  BASELINE config 3's recorded trace is played to move 5
+    on the HIP nets, the tree pickled, unpickled, given its nets back: moves 5..9 and every root-child visit count are still
+    the reference's; so are they on a deep copy taken at the same point, and on the original afterwards."""
+    import copy
+    import pickle
+    from bokego_amd import nnet
+    from bokego_amd.mcts_native import NativeMCTS, Position
+    t = json.load(open(os.path.join(GOLDEN, "mcts_trace.json")))["r1600"]
+    pi, val = nnet.HipPolicyNet(sds[0]), nnet.HipValueNet(sds[1])
+
+    def step(tree, ref):
+        tree.rollout(t["rollouts"])
+        assert {m: n for m, (n, _) in tree.child_stats().items()} == {int(k): v for k, v in ref["child_N"].items()}
+        assert abs(tree.winrate() - ref["root_winrate"]) < 1e-4
+        assert tree.choose().last_move == ref["move"]
+
+    tree = NativeMCTS(Position(), pi, val)
+    for ref in t["moves"][:5]:
+        step(tree, ref)
+    blob = pickle.dumps(tree)
+    twin = copy.deepcopy(tree)
+    back = pickle.loads(blob)
+    assert back.policy_net is None and back.evaluator is None and len(blob) > 100_000
+    back.policy_net, back.value_net = pi, val
+    for who in (back, twin, tree):
+        for ref in t["moves"][5:]:
+            step(who, ref)
+    assert back.evaluator.engine is tree.evaluator.engine          # rebuilt from the same fused nets
+    assert back.child_stats() == twin.child_stats() == tree.child_stats()
+
+
 @pytest.mark.parametrize("precision,kw", [("f16x2", {}), ("f32", {"speculate": 60, "speculate_rows": 256, "request_tasks": 0}), ("f32", {})])
 def test_config3_with_evaluation_ahead_of_expansion(sds, precision, kw):
     """search_params.speculate (the default of NativeMCTS on an f16x2 engine; forced here for fp32 in its whole-candidate

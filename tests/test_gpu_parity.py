@@ -367,7 +367,7 @@ def test_split_launch_is_bit_identical(precision, monkeypatch):
     outs = {}
     for split in (True, False):
         if not split:
-            monkeypatch.setenv("BK_NO_SPLIT", "1")
+            eng.set_option("no_split", 1)
         res = []
         for B, npol in ((1500, 1500), (1500, 40), (1201, 0), (900, 900), (771, 3), (1000, 0)):
             s0 = eng.stats()["split_launches"]
@@ -431,10 +431,10 @@ def test_every_workgroup_size_gives_the_same_bits(precision, monkeypatch):
     x = make_batch(700, seed_base=123_000, dtype=np.uint8)
     pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
     eng = LeafEngine(pw, vw, max_batch=1024, precision=precision)
-    monkeypatch.setenv("BK_NO_SPLIT", "1")
+    eng.set_option("no_split", 1)
     outs = {}
     for nb in (1, 2, 3):
-        monkeypatch.setenv("BK_FORCE_NB", str(nb))
+        eng.set_option("force_nb", nb)
         outs[nb] = [eng.eval(x[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
                     for B, npol in ((1, 1), (2, 2), (5, 3), (82, 1), (163, 163), (700, 700), (697, 50))]
     eng.close()
@@ -459,14 +459,14 @@ def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
     x = make_batch(128, seed_base=321_000, dtype=np.uint8)
     pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
     eng = LeafEngine(pw, vw, max_batch=256)
-    monkeypatch.setenv("BK_COOP", "0")
+    eng.set_option("coop", 0)
     ref = _small_batches(eng, x)
     assert eng.stats()["coop_launches"] == 0
     for mode in (None, "2", "3", "4", "6", "8", "12"):
         if mode is None:
-            monkeypatch.delenv("BK_COOP")
+            eng.set_option("coop", -1)
         else:
-            monkeypatch.setenv("BK_COOP", mode)
+            eng.set_option("coop", int(mode))
         c0 = eng.stats()["coop_launches"]
         got = _small_batches(eng, x)
         assert eng.stats()["coop_launches"] - c0 >= (13 if mode in (None, "2", "3") else 6), mode
@@ -476,9 +476,9 @@ def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
     assert eng.stats()["coop_fallbacks"] == 0
     # f32 feature planes through the same path; and the goldens' empty board
     xf = x[:40].astype(np.float32)
-    monkeypatch.delenv("BK_COOP")
+    eng.set_option("coop", -1)
     a = eng.eval(xf, logits=True, probs=True, value=True)
-    monkeypatch.setenv("BK_COOP", "0")
+    eng.set_option("coop", 0)
     b = eng.eval(xf, logits=True, probs=True, value=True)
     assert all(np.array_equal(a[k], b[k]) for k in a)
     eng.close()
@@ -517,21 +517,21 @@ def test_three_boards_on_two_or_four_cus_give_the_same_bits(monkeypatch):
     """Requests between the whole-board forms' ranges (129..192 and 257..384 tasks) run as groups of three boards of one net
     shared by 4 resp. 2 CUs (bk_leaf_eval_coop3_kernel: output channels split, the 3-board tile set, the cooperative
     exchange): every output bit-identical to the whole-board forms (BK_COOP3=0), partial groups, policy rows and both forced
-    forms included; a deserting peer ends in the usual fallback with the usual bits."""
+    forms included.  (A deserting peer ending in the usual fallback: tests/test_gpu_hooks.py, on the fault-injection build.)"""
     from bokego_amd.engine import LeafEngine
     from bokego_amd.workload import make_batch
     x = make_batch(384, seed_base=77_000, dtype=np.uint8)
     pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
     eng = LeafEngine(pw, vw, max_batch=512)
     shapes = ((128, 1), (131, 0), (150, 2), (170, 10), (186, 6), (256, 1), (257, 0), (299, 31), (340, 30), (378, 6))
-    monkeypatch.setenv("BK_COOP3", "0")
+    eng.set_option("coop3", 0)
     ref = [eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol) for B, npol in shapes]
     assert eng.stats()["coop_launches"] == 0
     for mode in (None, "2", "4"):
         if mode is None:
-            monkeypatch.delenv("BK_COOP3")
+            eng.set_option("coop3", -1)
         else:
-            monkeypatch.setenv("BK_COOP3", mode)
+            eng.set_option("coop3", int(mode))
         c0 = eng.stats()["coop_launches"]
         for (B, npol), want in zip(shapes, ref):
             if mode == "4" and B + npol > 192:
@@ -541,43 +541,6 @@ def test_three_boards_on_two_or_four_cus_give_the_same_bits(monkeypatch):
                 assert np.array_equal(want[k], got[k]), (mode, B, npol, k)
         assert eng.stats()["coop_launches"] - c0 == (10 if mode != "4" else 5), mode
     assert eng.stats()["coop_fallbacks"] == 0
-    monkeypatch.delenv("BK_COOP3")
-    c0 = eng.stats()["coop_launches"]
-    monkeypatch.setenv("BK_COOP_FAULT", "1")
-    bad = [eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol) for B, npol in ((150, 2), (340, 30))]
-    monkeypatch.delenv("BK_COOP_FAULT")
-    st = eng.stats()
-    assert st["coop_fallbacks"] == 2 and st["coop_launches"] - c0 == 2
-    good = eng.eval(x[:340], logits=True, probs=True, value=True, n_policy=30)
-    assert eng.stats()["coop_fallbacks"] == 2
-    for k in ref[2]:
-        assert np.array_equal(ref[2][k], bad[0][k]) and np.array_equal(ref[8][k], bad[1][k]) and np.array_equal(ref[8][k], good[k]), k
-    eng.close()
-
-
-def test_cooperative_form_falls_back_when_a_peer_never_arrives(monkeypatch):
-    """BK_COOP_FAULT makes one slice of one board leave before a meeting point: its peers give up after the bounded
-    wait and raise the flag that travels with the outputs, bk_wait redoes the request with one CU per board
-    (bk_stats().coop_fallbacks), the
-    outputs are the usual bits, and the next cooperative launch finds its counters clean."""
-    from bokego_amd.engine import LeafEngine
-    from bokego_amd.workload import make_batch
-    x = make_batch(48, seed_base=5_000, dtype=np.uint8)
-    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
-    eng = LeafEngine(pw, vw, max_batch=64)
-    monkeypatch.setenv("BK_COOP", "0")
-    ref = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
-    monkeypatch.delenv("BK_COOP")
-    monkeypatch.setenv("BK_COOP_FAULT", "1")
-    bad = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
-    monkeypatch.delenv("BK_COOP_FAULT")
-    st = eng.stats()
-    assert st["coop_fallbacks"] == 1 and st["coop_launches"] == 1
-    good = eng.eval(x, logits=True, probs=True, value=True, n_policy=5)
-    st = eng.stats()
-    assert st["coop_fallbacks"] == 1 and st["coop_launches"] == 2
-    for k in ref:
-        assert np.array_equal(ref[k], bad[k]) and np.array_equal(ref[k], good[k]), k
     eng.close()
 
 
@@ -609,36 +572,6 @@ def test_f16x2_overflow_flags_are_per_call_across_caller_streams(weights, gold):
     exact.close()
 
 
-def test_cooperative_failure_is_sticky_for_requests_queued_behind_it(monkeypatch):
-    """A is submitted with a deserting slice, B and C right behind it, all three cooperative, before
-    anything is waited for.  A's peers time out and raise the engine's poison word; B and C run before the host has
-    cleared the counters, see the word at entry, flag themselves and are redone by bk_wait as well: nobody hands out
-    results computed on stale counters.  D, submitted after the waits, is an ordinary clean cooperative launch."""
-    from bokego_amd.engine import LeafEngine
-    from bokego_amd.workload import make_batch
-    xs = [make_batch(n, seed_base=6_000 + 100 * i, dtype=np.uint8) for i, n in enumerate((48, 30, 62, 17))]
-    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
-    eng = LeafEngine(pw, vw, max_batch=64)
-    monkeypatch.setenv("BK_COOP", "0")
-    refs = [eng.eval(x, logits=True, probs=True, value=True, n_policy=3) for x in xs]
-    monkeypatch.delenv("BK_COOP")
-    monkeypatch.setenv("BK_COOP_FAULT", "1")
-    tA = eng.submit(xs[0], logits=True, probs=True, value=True, n_policy=3)
-    monkeypatch.delenv("BK_COOP_FAULT")
-    tB = eng.submit(xs[1], logits=True, probs=True, value=True, n_policy=3)
-    tC = eng.submit(xs[2], logits=True, probs=True, value=True, n_policy=3)
-    outs = [eng.wait(tA), eng.wait(tB), eng.wait(tC)]
-    st = eng.stats()
-    assert st["coop_launches"] == 3 and st["coop_fallbacks"] == 3
-    outs.append(eng.eval(xs[3], logits=True, probs=True, value=True, n_policy=3))
-    st = eng.stats()
-    assert st["coop_launches"] == 4 and st["coop_fallbacks"] == 3
-    for ref, out in zip(refs, outs):
-        for k in ref:
-            assert np.array_equal(ref[k], out[k]), k
-    eng.close()
-
-
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
 def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, monkeypatch, precision):
     """A large request of host planes is staged by a pool of copy threads and launched in two parts (the first 768
@@ -654,11 +587,11 @@ def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, m
     def run(B, npol, dt):
         x = x8[:B].astype(dt)
         return eng.eval(x, logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
-    monkeypatch.setenv("BK_NO_HEAD_PART", "1")
-    monkeypatch.setenv("BK_COPY_THREADS", "0")
+    eng.set_option("no_head_part", 1)
+    eng.set_option("copy_threads", 0)
     ref = {c: run(*c) for c in cases}
-    monkeypatch.delenv("BK_NO_HEAD_PART")
-    monkeypatch.delenv("BK_COPY_THREADS")
+    eng.set_option("no_head_part", 0)
+    eng.set_option("copy_threads", 6)
     for c in cases:
         got = run(*c)
         for k in ref[c]:
@@ -687,9 +620,9 @@ def test_small_requests_without_copies_give_the_same_bits(weights, monkeypatch):
     def run(kind, B, npol):
         kw = dict(logits=npol > 0, probs=npol > 0, value=True, n_policy=npol)
         return eng.wait(eng.submit_positions(recs[:B], **kw)) if kind == "pos" else eng.eval(x8[:B], **kw)
-    monkeypatch.setenv("BK_NO_DIRECT", "1")
+    eng.set_option("no_direct", 1)
     ref = {(k, *sh): run(k, *sh) for k in ("pos", "planes") for sh in shapes}
-    monkeypatch.delenv("BK_NO_DIRECT")
+    eng.set_option("no_direct", 0)
     for key, want in ref.items():
         got = run(*key)
         for k in want:

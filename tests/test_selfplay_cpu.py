@@ -22,11 +22,15 @@ class FakeNets:
         self.Wp = (rng.standard_normal((2187, 81)) * 0.05).astype(np.float32)
         self.wv = (rng.standard_normal(2187) * 0.02).astype(np.float32)
 
+    # row by row: like the engine's (and unlike a batched BLAS product's), a row's output does not depend on the batch it
+    # travels in -- the statistics vector is compared bit for bit across world sizes, backed-up value sums included
     def policy(self, x):
-        return np.asarray(x, np.float32).reshape(len(x), -1) @ self.Wp
+        x = np.asarray(x, np.float32).reshape(len(x), -1)
+        return np.stack([r @ self.Wp for r in x]) if len(x) else np.zeros((0, 81), np.float32)
 
     def value(self, x):
-        return np.tanh(np.asarray(x, np.float32).reshape(len(x), -1) @ self.wv)
+        x = np.asarray(x, np.float32).reshape(len(x), -1)
+        return np.tanh(np.array([r @ self.wv for r in x], np.float32))
 
 
 class _Wrap:
@@ -140,7 +144,12 @@ def test_end_of_generation_allreduce_world2_gloo():
     totals = [r[1] for r in res]
     assert totals[0] == totals[1]                                   # every rank holds the reduced vector
     assert totals[0]["games"] == 7 and totals[0]["plies"] == s1[3] and totals[0]["value_evals"] == s1[5]
-    assert totals[0]["first_move_hist"] == s1[len(selfplay.STATS_FIELDS):].astype(int).tolist()
+    nf = len(selfplay.STATS_FIELDS)
+    assert totals[0]["first_move_hist"] == s1[nf:nf + 81].astype(int).tolist()
+    # the visit / value statistics north_star asks the all-reduce for: summed over both ranks = the one-rank generation's
+    assert totals[0]["root_visit_hist"] == s1[nf + 81:nf + 162].astype(int).tolist() and sum(totals[0]["root_visit_hist"]) > 0
+    assert totals[0]["n_root_values"] == s1[10] == totals[0]["plies"]
+    assert totals[0]["sum_root_value"] == s1[8] and totals[0]["sum_abs_root_value"] == s1[9] > 0
     merged = {}
     for r in res:
         merged.update(r[2])
@@ -459,3 +468,95 @@ def test_simulation_mode_pools_do_not_depend_on_grouping_threads_or_record_path(
     assert play([seeds], 3, branch_num=6) == few and few != alone
     with_prune = play([seeds], 2, prune=1)
     assert {s: m for s, (m, _) in with_prune.items()} == {s: m for s, (m, _) in alone.items()}
+
+
+def test_visit_and_value_statistics_of_a_generation():
+    """VERDICT r4 missing #3: the reduced vector carries what north_star names -- "visit/value statistics": the histogram of
+    root-child visit counts over every ply of every game (recomputed here from the per-ply visit records), and the sum / sum of
+    magnitudes / count of the root's mean backed-up value at every move.  The value sums are kept in 2^-32 fixed point: totals
+    over any partition of the games are equal BIT FOR BIT (the world-size test above compares whole vectors)."""
+    f = FakeNets()
+    local, total = selfplay.self_play(selfplay.CallableEvaluator(f.policy, f.value), record_visits=1, **KW)
+    hist = np.zeros(81, np.int64)
+    for g, plies in local["visits"].items():
+        for v in plies:
+            for mv, n in v.items():
+                hist[mv] += n
+    assert total["root_visit_hist"] == hist.tolist() and hist.sum() > 7 * 10 * 30
+    assert total["n_root_values"] == total["plies"] == 70
+    assert abs(total["sum_root_value"]) <= total["sum_abs_root_value"] <= 70 and total["sum_abs_root_value"] > 0
+    assert total["mean_abs_root_value"] == total["sum_abs_root_value"] / 70
+    assert selfplay.STATS_LEN == 11 + 162 and selfplay.STATS_LEN * 8 < 2048                     # SURVEY 8e: "< 2 KB"
+    # every entry is a multiple of 2^-32: the sums cannot depend on the order of addition
+    assert np.array_equal(local["local_stats"] * 2.0 ** 32, np.round(local["local_stats"] * 2.0 ** 32))
+    # one game's own statistics: n_root_values = its plies; a pool that has not moved yet reports zeros
+    pool = selfplay.GamePool([3], selfplay.search_params(rollouts=10, max_turns=3), cap=256, threads=1)
+    rv, sv, sa, nv = pool.game_stats(0)
+    assert rv.sum() == 0 and (sv, sa, nv) == (0.0, 0.0, 0)
+    selfplay.run_pools([pool], selfplay.CallableEvaluator(f.policy, f.value))
+    rv, sv, sa, nv = pool.game_stats(0)
+    assert nv == len(pool.moves(0)) == 4 and rv.sum() >= 4 * 9
+    with pytest.raises(IndexError):
+        pool.game_stats(1)
+
+
+def test_native_step_loop_plays_the_same_games():
+    """VERDICT r4 next #3a: bk_pools_run -- collect, submit, wait, normalise, deliver in C, no interpreter between two steps -- is
+    the Python loop run_pools: the same games move for move, the same per-game evaluation counts, the same reduced statistics,
+    for one, two and three pools, with and without in-batch de-duplication and a task cap (the evaluator here is a Python
+    callback around the fake nets; on the GPU box it is the engine's own bk_evaluator: tests/test_gpu_selfplay.py)."""
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    kw = dict(n_games=12, rollouts=40, expand_thresh=6, noise_weight=0.25, sample_plies=3, max_turns=11, cap=300, threads=2, eager_top=4,
+              record_visits=1)
+    runs = {}
+    for native in (False, True):
+        for n_pools, extra in ((1, {}), (2, {}), (3, dict(dedup=True)), (2, dict(task_cap=40, dedup=True))):
+            ev = selfplay.RecordEvaluator(pol, val)
+            local, total = selfplay.self_play(ev, n_pools=n_pools, native_loop=native, **kw, **extra)
+            assert local["native_loop"] is native
+            runs[(native, n_pools, tuple(extra))] = (local["games"], local["visits"], total, local["steps"], ev.positions)
+    base = runs[(False, 1, ())]
+    for key, r in runs.items():
+        assert r[0] == base[0] and r[1] == base[1] and r[2] == base[2], key
+    for (native, n_pools, extra), r in runs.items():
+        if native:
+            py = runs[(False, n_pools, extra)]
+            assert r[3] == py[3] and r[4] == py[4], (n_pools, extra)           # the same batches, too
+    # an evaluator that raises inside the C loop: the exception comes out of the call, nothing hangs
+    class Boom(selfplay.RecordEvaluator):
+        def finish(self, handle, normalise=None):
+            raise KeyError("boom")
+    with pytest.raises(KeyError):
+        selfplay.self_play(Boom(pol, val), native_loop=True, **kw)
+    # planes-only evaluators are refused with a clear message (the C loop hands over position records)
+    with pytest.raises(TypeError):
+        selfplay.self_play(selfplay.CallableEvaluator(f.policy, f.value), native_loop=True, **kw)
+
+
+def test_normalise_rows_is_categoricals_division():
+    """bk_normalise_rows: p / sum(p) per row with the sum taken left to right in fp32 -- at most an ulp from torch's own
+    Categorical normalisation (nnet.py:274), and the same bits on every host (torch's vectorised sum depends on the CPU)."""
+    rng = np.random.default_rng(0)
+    p = (rng.random((64, 81)).astype(np.float32) ** 6) * rng.random((64, 1)).astype(np.float32)
+    a, b = selfplay.normalise_rows(p), selfplay.normalise_like_categorical(p)
+    want = np.stack([row / np.float32(sum(np.float32(x) for x in row)) for row in p])      # the contract, literally
+    acc = np.zeros(64, np.float32)
+    for k in range(81):
+        acc = acc + p[:, k]
+    assert np.array_equal(a, p / acc[:, None]) and np.array_equal(a, want)
+    assert np.abs(a - b).max() <= 2 * np.finfo(np.float32).eps and np.abs(a.sum(1) - 1).max() < 1e-6
+    assert selfplay.normalise_rows(np.zeros((0, 81), np.float32)).shape == (0, 81)
+
+
+def test_a_pool_whose_constructor_failed_has_a_quiet_destructor(capsys):
+    """GamePool.__del__ -> close() read self._h unconditionally; a constructor that raised before the
+    handle existed then printed an AttributeError from the destructor."""
+    import gc
+    with pytest.raises(Exception):
+        selfplay.GamePool("not seeds", selfplay.search_params())
+    gc.collect()
+    assert "AttributeError" not in capsys.readouterr().err
+    p = selfplay.GamePool.__new__(selfplay.GamePool)
+    p.close()                                                       # no handle: nothing to do, no error

@@ -33,10 +33,7 @@ def timed(B, npol, reps=20):
 for B, npol in ((126, 3), (128, 1), (150, 2), (170, 10), (186, 6), (190, 1), (200, 8), (250, 6), (256, 1), (300, 20), (340, 30), (370, 14), (380, 4), (383, 1), (400, 10), (500, 12)):
     row = []
     for forced in ("0", None):
-        if forced is None:
-            os.environ.pop("BK_COOP3", None)
-        else:
-            os.environ["BK_COOP3"] = forced
+        eng.set_option("coop3", -1 if forced is None else int(forced))
         us, coop, fb, same = timed(B, npol)
         row.append(f"{'whole-board forms' if forced == '0' else 'default':>17s} {us:7.1f} us (cooperative launches {coop}, fallbacks {fb}, bits {'equal' if same else 'DIFFER'})")
     print(f"B {B:4d} + {npol:2d} policy rows = {B + npol:4d} tasks: " + " | ".join(row), flush=True)
