@@ -581,7 +581,9 @@ def fold_counter_rows(rows, tot):
         per = {}
         for x in v:
             per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
+        kind = v[0]["Kernel_Name"].split("(")[0].strip() + f" grid {v[0]['Grid_Size']}"
         for c, vals in per.items():
+            tot.setdefault("_by_launch", {}).setdefault(kind, {})[c] = sum(a for a, _ in vals) / len(vals)
             tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
             tot["_ns_" + c] = tot.get("_ns_" + c, 0.0) + sum(b for _, b in vals) / len(vals)   # the kernels' durations in THIS pass
             if c == "GRBM_GUI_ACTIVE":
@@ -629,6 +631,11 @@ def live_counters(batch, precision, timeout_s=150, device=0):
                      f"launch ({time.perf_counter() - t0:.0f} s)", "counters_per_step": {k: v for k, v in tot.items() if not k.startswith("_")}}
     if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
         out["hbm_traffic_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
+        # ... and launch by launch: the 2-board tail's bytes and every write are the same in every run; what moves from run to
+        # run and box to box (177-179 MB on one box, 188 MB in the round-4 driver run) is the 3-board launch's read traffic --
+        # how often each XCD's 4 MB L2 re-fetches its net's 3.9 MB weight stream during the ten rounds (tools/pmc_traffic.sh)
+        out["hbm_traffic_bytes_by_launch"] = {k: (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024
+                                              for k, c in tot.get("_by_launch", {}).items() if "FETCH_SIZE" in c or "WRITE_SIZE" in c}
     if tot.get("GRBM_GUI_ACTIVE") and tot.get("_ns"):
         out["effective_clock_ghz"] = tot["GRBM_GUI_ACTIVE"] / 8 / tot["_ns"]
         # the CHILD's own kernel time per step (profiler timestamps), in the clock pass and in the MFMA-counter pass: the
@@ -677,7 +684,8 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
         if live.get("executed_mfma_flop_per_launch") and precision == "f32":
             pmc.pop("executed_mfma_flop_per_workgroup", None)
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-         "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "traffic_source": pmc.get("source"), "kernel": KERNEL[precision],
+         "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "traffic_by_launch": (live or {}).get("hbm_traffic_bytes_by_launch"),
+         "traffic_source": pmc.get("source"), "kernel": KERNEL[precision],
          "kernel_ms": kern_ms, "kernel_ms_isolated_p10_p50_p90": spread,
          "algorithmic_flop_per_launch": batch * FLOP_PER_LEAF, "algorithmic_hbm_bytes_per_launch": batch * BYTES_PER_LEAF,
          "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"), "pmc_source": pmc.get("source"),

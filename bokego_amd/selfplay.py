@@ -105,7 +105,9 @@ TREE_SYMBOLS = {
     "bk_pool_game_stats": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(GameStats)]),
     "bk_pool_snapshot": (ctypes.c_long, [_VP, ctypes.c_int, _VP, ctypes.c_long]),
     "bk_pool_restore": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_long]),
-    "bk_pools_run": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(EvaluatorStruct), ctypes.c_int, ctypes.POINTER(RunInfo)]),
+    # (the evaluator as a plain pointer: under `python -m bokego_amd.selfplay` this module exists twice -- as __main__ and as
+    # bokego_amd.selfplay, which engine.evaluator() imports -- and a typed pointer would reject the other copy's struct)
+    "bk_pools_run": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.c_int, ctypes.POINTER(RunInfo)]),
     "bk_normalise_rows": (None, [_VP, ctypes.c_int]),
 }
 _tree_ready = False
@@ -559,6 +561,19 @@ EAGER_TOP = {"f32": 4, "f16x2": 6}
 EAGER_TOP_F32_MANY_GAMES = (192, 2)       # from this many games per rank: this many children
 
 
+def small_shard_defaults(precision, eager_top, pool_games):
+    """(speculate, task_cap) for a pool of `pool_games` games on an fp32 engine: (0, 0) except where a pool's request (~3 tasks
+    per game and step with 4 children per expansion) falls into the 2-CUs-per-board launch's range, 81..128 tasks, whose time
+    (174 us) does not depend on the size: there a leaf that reaches 70 visits sends its policy row -- and then its best-prior
+    children -- along with requests that go out anyway (bk_search_params.speculate: its expansion at 100 visits needs no round
+    trip of its own; the same search) and the batch is held to 128 tasks.  Measured on one MI355X, a rank's 64 games of the
+    512-game job (two pools of 32): 1,085 steps of ~85 rows -> 1,009 of ~98, 0.181 -> 0.171 s (profiles/r05_spec_probe.txt; without
+    the cap the batches cross 128 tasks: 0.190 s; 128 games per rank, two pools of 64: no gain, left off)."""
+    if precision == "f32" and eager_top and eager_top > 2 and 64 < 3 * pool_games <= 128:
+        return 70, 128
+    return 0, 0
+
+
 def default_eager_top(precision, n_games_here):
     if precision == "f32" and n_games_here >= EAGER_TOP_F32_MANY_GAMES[0]:
         return EAGER_TOP_F32_MANY_GAMES[1]
@@ -581,28 +596,45 @@ def shard_game_ids(n_games, rank, world):
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
               reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None,
-              dedup=None, native_loop=None):
+              dedup=None, native_loop=None, pool_sizes=None, speculate=None, speculate_rows=8):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
     a later job) with the same games coming out; the reference's launcher can only raise when a worker fails
     (bin/selfplay.py:196-199).  The statistics returned are those of the games played here.
     native_loop: the step loop in C (run_pools_native) instead of in Python (run_pools); the same games either way.
-    Default: C whenever the evaluator takes position records and nobody asked for per-step progress calls."""
+    Default: C whenever the evaluator takes position records and nobody asked for per-step progress calls.
+    pool_sizes: how many of this rank's games each pool gets (a list summing to the rank's games; task_cap may then be a list
+    too, one per pool).  Default: n_pools equal pools (unequal ones, sized so that each pool's requests land on the cheap side
+    of the launch forms' size steps, were measured and gain nothing: profiles/r05_pool_split.txt).
+    speculate: evaluation ahead of expansion in the pools (bk_search_params.speculate; None: small_shard_defaults())."""
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
     if eager_top is None:
         eager_top = default_eager_top(precision, len(gids))
-    prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
-                        sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
-                        eager_top=eager_top)
     if n_pools is None:
         # two pools: the host advances one while the GPU evaluates the other's batch.  (Rounds 1-2, every child evaluated: three
         # pools paid off for f16x2 from ~200 games per rank; with the best-prior children only, batches are 5x smaller and
         # two fuller ones win in both precisions: f16x2 59.3 k against 51.5 k games/min, fp32 25.9 k against 19.7 k)
         n_pools = 2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
-    parts = [gids[i::n_pools] for i in range(n_pools)]
+    biggest_pool = max(pool_sizes) if pool_sizes else -(-len(gids) // max(1, n_pools))
+    small = small_shard_defaults(precision, eager_top, biggest_pool)
+    if speculate is None:
+        speculate = small[0]
+    prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
+                        sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
+                        eager_top=eager_top, speculate=speculate, speculate_rows=speculate_rows)
+    if pool_sizes is not None:
+        pool_sizes = [int(k) for k in pool_sizes if int(k) > 0]
+        if sum(pool_sizes) != len(gids):
+            raise ValueError(f"pool_sizes {pool_sizes} do not add up to this rank's {len(gids)} games")
+        n_pools, parts, at = len(pool_sizes), [], 0
+        for k in pool_sizes:
+            parts.append(gids[at:at + k])
+            at += k
+    else:
+        parts = [gids[i::n_pools] for i in range(n_pools)]
     pools = [GamePool([seed_base + g for g in part], prm, cap=cap, threads=threads) for part in parts]
     if task_cap is None:
         # fp32 engine: a step's launch costs whole rounds of 3-board workgroups (0.75 ms per 768 tasks on 256 CUs), and a batch
@@ -615,6 +647,8 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         if precision == "f32" and 0 < eager_top <= 2:
             # ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups (256 / 512 / 768 tasks on 256 CUs)
             task_cap = n_cu * max(1, round(2.0 * biggest / n_cu)) - 4
+        elif small[1] and speculate:
+            task_cap = small[1]                   # a 22..42-game pool, evaluation ahead on: requests stay within the 2-CUs-per-board launch
         elif precision == "f32" and eager_top and n_cu == 256 and 128 < 3 * biggest <= 192:
             # a 64-game pool (a rank's share at 4 ranks) asks for ~190 tasks per step: within the range where groups of three
             # boards share 4 CUs (249 us) instead of just over it (a round of one-board workgroups, 298 us): 0.315 -> 0.304 s
@@ -623,8 +657,9 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
             task_cap = per_round * max(1, round(3.0 * biggest / per_round)) - 4 if (precision == "f32" and eager_top) else 0
     if dedup is None:
         dedup = os.environ["BK_DEDUP"] == "1" if "BK_DEDUP" in os.environ else DEDUP.get(precision, False)
-    for pool in pools:
-        pool.set_task_cap(task_cap)
+    caps = list(task_cap) if isinstance(task_cap, (list, tuple)) else [task_cap] * len(pools)
+    for pool, tc in zip(pools, caps):
+        pool.set_task_cap(tc)
         pool.set_dedup(dedup and getattr(evaluator, "wants_positions", False))
     if native_loop is None:
         native_loop = NATIVE_LOOP and progress is None and getattr(evaluator, "wants_positions", False)
@@ -647,7 +682,7 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         p.close()
     named = named_stats(total)
     return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local, "native_loop": bool(native_loop),
-             "n_pools": n_pools, "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
+             "n_pools": n_pools, "speculate": int(speculate), "task_caps": [int(c or 0) for c in caps], "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
 
 
 # ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------

@@ -66,6 +66,14 @@ int main(int argc, char **argv) {
     const int f32 = !(getenv("BK_PRECISION") && strcmp(getenv("BK_PRECISION"), "f16x2") == 0);
     if (f32 && mine_n >= 192) prm.eager_top = 2;   /* fp32 from 192 games per rank: two children (selfplay.py, EAGER_TOP) */
 
+    /* a pool of 22..42 games on the fp32 engine asks for 81..128 tasks per step -- the 2-CUs-per-board launch, whose time does
+     * not depend on the size: a leaf that reaches 70 visits sends its policy row and then its best children along with requests
+     * that go out anyway (evaluation ahead of expansion, the same search), and the batch is held to 128 tasks
+     * (selfplay.small_shard_defaults; profiles/r05_spec_probe.txt: 64 games per rank 0.181 -> 0.171 s) */
+    const int per_pool = (mine_n + 1) / 2;
+    const int small_shard = f32 && prm.eager_top > 2 && 3 * per_pool > 64 && 3 * per_pool <= 128;
+    if (small_shard) { prm.speculate = 70; prm.speculate_rows = 8; }
+
     /* this rank's games, dealt to the pools round-robin */
     slot_t s[NPOOLS];
     uint64_t *seeds = malloc(sizeof(uint64_t) * (n_games + 1));
@@ -87,7 +95,9 @@ int main(int argc, char **argv) {
         {
             const char *pe2 = getenv("BK_PRECISION");
             if (!(pe2 && strcmp(pe2, "f16x2") == 0)) {
-                if (prm.eager_top <= 2) {          /* ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups */
+                if (small_shard) {
+                    bk_pool_set_task_cap(s[i].pool, 128);
+                } else if (prm.eager_top <= 2) {   /* ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups */
                     int rounds = (2 * k + 128) / 256;
                     bk_pool_set_task_cap(s[i].pool, 256 * (rounds < 1 ? 1 : rounds) - 4);
                 } else if (3 * k > 128 && 3 * k <= 192) {

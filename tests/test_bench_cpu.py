@@ -175,6 +175,8 @@ def test_counter_rows_fold_into_per_step_values():
     tot = {}
     assert bench.fold_counter_rows(rows(head, 1310720, 8, "FETCH_SIZE", 49000, 7_500_000) + rows(tail, 131072, 8, "FETCH_SIZE", 37000, 530_000)
                                    + rows(head, 91648, 1, "FETCH_SIZE", 9999, 800_000), tot)
+    by = tot.pop("_by_launch")                          # the same figures launch by launch (the 3-board rounds / the 2-board tail)
+    assert sorted(c["FETCH_SIZE"] for c in by.values()) == [37000.5, 49000.5] and all("grid" in k for k in by)
     assert tot == {"FETCH_SIZE": 49000.5 + 37000.5, "_ns_FETCH_SIZE": 8_030_000.0}     # + the kernels' durations in this counter's pass
     assert bench.fold_counter_rows(rows(head, 1310720, 8, "GRBM_GUI_ACTIVE", 1.43e8, 7_500_000) + rows(tail, 131072, 8, "GRBM_GUI_ACTIVE", 1.0e7, 530_000), tot)
     assert tot["_ns"] == 8_030_000 and abs(tot["GRBM_GUI_ACTIVE"] - (1.43e8 + 1.0e7 + 1)) < 1e-3

@@ -306,3 +306,19 @@ def test_in_batch_deduplication_on_the_engine_plays_the_same_games():
     local, _ = selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=16, rollouts=50, cap=8192)
     assert not local["dedup"]
     eng.close()
+
+
+def test_a_ranks_share_at_eight_ranks_plays_its_games_with_evaluation_ahead(engine, generation):
+    """configs[3] at 8 ranks: rank 3's 64 games (two pools of 32: ~94-task requests, the 2-CUs-per-board launch) run with
+    evaluation ahead of expansion and batches held to 128 tasks by default (selfplay.small_shard_defaults; 0.181 -> 0.171 s,
+    profiles/r05_spec_probe.txt).  They are the games the one-rank generation played for those ids, move for move and visit for
+    visit, and the same as with evaluation ahead switched off -- in fewer steps."""
+    local, _ = generation
+    kw = dict(rank=3, world=8, record_visits=1, **CFG4)
+    on, _ = selfplay.self_play(selfplay.EngineEvaluator(engine), **kw)
+    off, _ = selfplay.self_play(selfplay.EngineEvaluator(engine), speculate=0, **kw)
+    assert on["speculate"] == 70 and on["task_caps"] == [128, 128] and off["speculate"] == 0
+    gids = selfplay.shard_game_ids(512, 3, 8)
+    assert sorted(on["games"]) == gids and on["games"] == off["games"] == {g: local["games"][g] for g in gids}
+    assert on["visits"] == off["visits"] == {g: local["visits"][g] for g in gids}
+    assert on["steps"] < off["steps"]

@@ -560,3 +560,27 @@ def test_a_pool_whose_constructor_failed_has_a_quiet_destructor(capsys):
     assert "AttributeError" not in capsys.readouterr().err
     p = selfplay.GamePool.__new__(selfplay.GamePool)
     p.close()                                                       # no handle: nothing to do, no error
+
+
+def test_evaluation_ahead_in_the_pools_plays_the_same_games():
+    """Round 5: a rank's small share of configs[3] (two pools of 32 games) runs with evaluation ahead of expansion
+    (bk_search_params.speculate, round 3's one-tree feature) inside the lock-step pools: fewer steps at the same launch cost.
+    The networks are pure functions and the tree is not touched, so the games are the same games -- moves, scores, every ply's
+    root visit counts -- whatever the threshold; only the evaluation and request counts differ."""
+    f = FakeNets()
+    runs = {}
+    kw = dict(KW, expand_thresh=12, rollouts=80)
+    for spec in (0, 5, 9):
+        ev = selfplay.CallableEvaluator(f.policy, f.value)
+        local, total = selfplay.self_play(ev, eager_top=4, speculate=spec, record_visits=1, **kw)
+        assert local["speculate"] == spec
+        runs[spec] = (local["games"], local["visits"], total)
+    for spec in (5, 9):
+        assert runs[spec][0] == runs[0][0] and runs[spec][1] == runs[0][1], spec
+        assert all(runs[spec][2][k] == runs[0][2][k] for k in ("plies", "black_wins", "sum_score", "root_visit_hist", "sum_root_value")), spec
+        assert runs[spec][2]["value_evals"] > runs[0][2]["value_evals"]
+    # when it is on by default: fp32 engine, four children per expansion, a pool whose requests fall into 81..128 tasks
+    d = selfplay.small_shard_defaults
+    assert d("f32", 4, 32) == (70, 128) and d("f32", 4, 22) == (70, 128) and d("f32", 4, 42) == (70, 128)
+    assert d("f32", 4, 21) == (0, 0) and d("f32", 4, 43) == (0, 0) and d("f32", 4, 64) == (0, 0)
+    assert d("f32", 2, 32) == (0, 0) and d("f16x2", 6, 32) == (0, 0) and d("f32", 0, 32) == (0, 0)
