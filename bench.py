@@ -581,7 +581,9 @@ def fold_counter_rows(rows, tot):
         per = {}
         for x in v:
             per.setdefault(x["Counter_Name"], []).append((float(x["Counter_Value"]), int(x["End_Timestamp"]) - int(x["Start_Timestamp"])))
-        kind = v[0]["Kernel_Name"].split("(")[0].strip() + f" grid {v[0]['Grid_Size']}"
+        import re
+        m = re.search(r"bk_\w+(<[^>]*>)?", v[0]["Kernel_Name"])
+        kind = (m.group(0) if m else v[0]["Kernel_Name"][:48]) + f" grid {v[0]['Grid_Size']}"
         for c, vals in per.items():
             tot.setdefault("_by_launch", {}).setdefault(kind, {})[c] = sum(a for a, _ in vals) / len(vals)
             tot[c] = tot.get(c, 0.0) + sum(a for a, _ in vals) / len(vals)
@@ -733,6 +735,15 @@ def roofline(precision, batch, kern_ms, sust, spread, live=None):
     return r
 
 
+_T0 = time.time()
+
+
+def progress(what):
+    """one line per phase on stderr (rank 0 only): a long run shows where it is; BK_BENCH_QUIET=1: off"""
+    if os.environ.get("RANK", "0") == "0" and not os.environ.get("BK_BENCH_QUIET"):
+        print(f"bench.py [{time.time() - _T0:6.1f} s] {what}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -829,6 +840,7 @@ def main():
         return [float(o.item()) for o in outl]
 
     # ---- headline: exactly --steps launches of the reference-width kernel, then the sustained loop -------------
+    progress(f"engine up, workload made; timing {args.steps} steps")
     head = measure(eng, x, args.steps, args.warmup, barrier, reduce_max, args.sustain, torch)
     head_parity = parity_in_run(eng, torch)
     per_rank = gather(args.batch * args.steps / head["dt_local"])
@@ -840,6 +852,7 @@ def main():
     other = None
     other_name = "f16x2" if args.precision == "f32" else "f32"
     if not args.no_f16x2:
+        progress("headline timed; nested f16x2 block")
         eng.set_precision(other_name)
         m = measure(eng, x, args.steps, args.warmup, barrier, reduce_max, args.sustain, torch)
         other = {"value": world * args.batch * args.steps / m["dt"], "unit": "leaf-evals/s", "dtype": DTYPE[other_name],
@@ -929,6 +942,7 @@ def main():
                         "(children_evaluated_per_expansion: fp32 2 from 192 games per rank, else 4; f16x2 6)"}
         red = torch.device("cuda", local_rank) if backend == "nccl" else None
         # untimed: a small generation first (the pools' worker threads exist, the allocator and the caches are warm)
+        progress("self-play warm-up generation")
         selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=min(64 * world, args.selfplay_games), rollouts=50, rank=rank, world=world,
                            cap=8192, threads=threads, reduce_device=red)
 
@@ -962,6 +976,7 @@ def main():
 
         for prec in ([args.precision] if args.no_f16x2 else [args.precision, other_name]):
             eng.set_precision(prec)
+            progress(f"self-play, strong leg, {prec}: {args.selfplay_games} games over {world} rank(s)")
             sp[prec] = generation(args.selfplay_games, prec)          # STRONG scaling: the config's fixed 512 games over all ranks
         eng.set_precision(args.precision)
         # WEAK scaling: every rank plays its own full set (what the reference's workers do: cpu_count() processes, each with
@@ -970,6 +985,7 @@ def main():
         # both efficiencies can be read off this line: weak = min / max of per_rank_seconds against a 1-GPU run's `seconds`;
         # strong = (a rank's weak-leg seconds) / (n_gpus x the strong leg's seconds).
         if world > 1:
+            progress(f"self-play, weak leg: {args.selfplay_games} games per rank")
             sp["weak"] = dict(generation(args.selfplay_games * world, args.precision), precision=args.precision,
                               what=f"{args.selfplay_games} games PER RANK ({args.selfplay_games * world} in all), one all-reduce")
             one_rank = float(np.median(sp["weak"]["per_rank_seconds"]))
@@ -999,12 +1015,14 @@ def main():
         return
     dist = None
 
+    progress("collectives over; rank 0 alone: counter passes")
     live = None
     if not args.no_live_pmc:
         live = live_counters(args.batch, args.precision, device=local_rank)
 
     cpu = None
     if not args.no_cpu_baseline:
+        progress("CPU baselines")
         cpu = cpu_baseline(pw, vw, x_host, head_logits, head_values)
         if sp is not None:
             sp["cpu_baseline"] = selfplay_cpu_baseline(cpu["cores"])

@@ -128,12 +128,15 @@ def _gloo_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_end_of_generation_allreduce_world2_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_end_of_generation_allreduce_world2_gloo(world):
+    """the generation's one collective over gloo: world 2, and world 8 -- the node's size, with more ranks than games (one rank
+    plays nothing and still joins the all-reduce and the broadcast)"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -142,7 +145,7 @@ def test_end_of_generation_allreduce_world2_gloo():
         assert p.exitcode == 0
     g1, s1 = _run_world(1, **KW)
     totals = [r[1] for r in res]
-    assert totals[0] == totals[1]                                   # every rank holds the reduced vector
+    assert all(t == totals[0] for t in totals)                      # every rank holds the reduced vector
     assert totals[0]["games"] == 7 and totals[0]["plies"] == s1[3] and totals[0]["value_evals"] == s1[5]
     nf = len(selfplay.STATS_FIELDS)
     assert totals[0]["first_move_hist"] == s1[nf:nf + 81].astype(int).tolist()

@@ -81,8 +81,13 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
         # fp32 at B=4096 runs as 10 whole rounds of 3-board workgroups + a tail launch of 2-board ones (split launch):
         # bench.py's HIP events bracket both, so the per-step kernel time is the sum of the two rows
         tail = [r for r in rows if TAIL_OF.get(prec, "\0") in r["Name"]]
-        if tail and abs(int(tail[0]["Calls"]) - int(kern["Calls"])) <= 0.1 * int(kern["Calls"]):
-            tail_ms = (full_size_ms(TAIL_OF[prec]) or (float(tail[0]["AverageNs"]) / 1e6,))[0]
+        fs_tail = full_size_ms(TAIL_OF[prec]) if tail else None
+        # (the tail kernel also serves other legs of the bench -- 2-board rounds of the small-batch block: compare the counts of
+        # the two kernels' timed-batch grids where the per-dispatch trace is there, else the aggregate call counts)
+        same = (abs(fs_tail[1] - fs[1]) <= 0.1 * fs[1]) if (fs and fs_tail) else \
+            (tail and abs(int(tail[0]["Calls"]) - int(kern["Calls"])) <= 0.1 * int(kern["Calls"]))
+        if tail and same:
+            tail_ms = (fs_tail or (float(tail[0]["AverageNs"]) / 1e6,))[0]
             o.write(f"\n(split launch: `{kname}` avg {avg_ms:.4f} ms + tail `{TAIL_OF[prec]}` avg {tail_ms:.4f} ms per step)\n")
             avg_ms += tail_ms
         rf = blk["roofline"]
