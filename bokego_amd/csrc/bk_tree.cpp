@@ -1680,7 +1680,9 @@ void snapshot_game(const Game& gm, SnapWriter& w) {
     w.vec(gm.priors);
     const int32_t ints[8] = {gm.root, (int32_t)gm.state, gm.remaining, gm.pending_expand, gm.po, gm.po_mark, gm.po_reward, gm.row_cap};
     w.pod(ints);
-    w.vec(gm.path);
+    // (the last rollout's path is read again only while its leaf's value is out or its playout runs; after a re-rooting of a
+    // pruning tree its ids are stale -- every rollout starts with path.clear())
+    w.vec(gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT ? gm.path : std::vector<int>());
     w.vec(gm.req_policy);
     w.vec(gm.req_value);
     w.vec(gm.spec_queue);

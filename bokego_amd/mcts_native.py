@@ -203,8 +203,9 @@ class NativeMCTS:
                                           (lambda x: value_net(torch.from_numpy(x)).numpy().reshape(-1)))
 
     # ---- copies and pickles (mcts.py:81-108): the search state travels, the networks do not -----------------
-    _PLAIN = ("no_sim", "branch_num", "expand_thresh", "exploration_weight", "noise_weight", "value_net_weight", "komi",
-              "_spec_kw", "_spec_prec", "_has_value", "_max_batch", "_cap")
+    # what does not travel in a pickle / is not shared by a copy: the nets and the evaluator (mcts.py:93-96), and the handles
+    # and views of THIS object's native pool (a snapshot stands in for them)
+    _NOT_STATE = ("policy_net", "value_net", "evaluator", "_pool", "_lib", "N", "V", "Q", "children")
 
     def _adopt(self, blob, cap):
         """a fresh one-game pool holding the snapshot `blob` (its search parameters come with it)"""
@@ -215,9 +216,10 @@ class NativeMCTS:
         self.children = _ChildrenView(self)
 
     def __getstate__(self):
-        """MCTS.__getstate__ (mcts.py:93-96): everything but the nets -- here the native tree as a snapshot
-        (bk_pool_snapshot: nodes, edges, priors, N / V / Q, root, generator) and the keyword arguments."""
-        d = {k: getattr(self, k) for k in self._PLAIN}
+        """MCTS.__getstate__ (mcts.py:93-96): everything but the nets -- every attribute of the object (a subclass's too:
+        NativeGTP's protocol state) and the native tree as a snapshot (bk_pool_snapshot: nodes, edges, priors, N / V / Q, root,
+        generator)."""
+        d = {k: v for k, v in self.__dict__.items() if k not in self._NOT_STATE}
         d["snapshot"] = self._pool.snapshot(0)
         return d
 
@@ -233,9 +235,12 @@ class NativeMCTS:
     def __deepcopy__(self, memo):
         """MCTS.__deepcopy__ (mcts.py:81-90): an independent copy of the search state that shares the networks -- and here
         the evaluator (the engine) -- with the original."""
+        import copy
         new = self.__class__.__new__(self.__class__)
-        for k in self._PLAIN:
-            setattr(new, k, getattr(self, k))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._NOT_STATE:
+                setattr(new, k, copy.deepcopy(v, memo))
         new.policy_net, new.value_net, new.evaluator = self.policy_net, self.value_net, self.evaluator
         new._adopt(self._pool.snapshot(0), self._cap)
         return new

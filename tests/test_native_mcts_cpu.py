@@ -506,3 +506,32 @@ def test_a_snapshot_carries_a_self_play_game_across_pools():
         assert np.array_equal(ra[0], rb[0]) and ra[1:] == rb[1:]
         assert b.info(dst)["n_value_evals"] == ref.info(src)["n_value_evals"]
     assert len(b.moves(1)) == 4                                       # the pool's own game played by the pool's parameters
+    # a FINISHED game of a pruning tree (its last rollout's path is stale after the final re-rooting: found by `make tsan`'s
+    # driver) and a game that has not started both snapshot and restore
+    b.restore(1, ref.snapshot(0))
+    assert b.moves(1) == ref.moves(0) and b.info(1)["done"] == 1 and b.info(1)["score"] == ref.info(0)["score"]
+    fresh = selfplay.GamePool([9], prm, cap=256, threads=1)
+    b.restore(1, fresh.snapshot(0))
+    assert b.moves(1) == [] and b.info(1)["done"] == 0
+
+
+def test_the_default_launchers_tree_copies_and_pickles_with_its_protocol_state():
+    """NativeGTP = the GTP front-end on the native tree, what `python -m bokego_amd.gtp` runs: a deep copy and a pickle carry the
+    protocol's own state too (move history, komi, last root: the reference's MCTS.__getstate__ copies the whole __dict__,
+    mcts.py:93-96, and GTP is a subclass of it) and answer the rest of a session exactly as the original does."""
+    import copy
+    import pickle
+    f = FakeNets()
+    P, V = _Wrap(f.policy), _Wrap(f.value, True)
+    g = NativeGTP(Position(), P, V, no_sim=True, time_lim=None, n_rollouts=60, expand_thresh=8)
+    g.running = True
+    for cmd in ("komi 6.5", "play b e5", "genmove w", "play b c3"):
+        g.send(cmd)
+    twin = copy.deepcopy(g)
+    back = pickle.loads(pickle.dumps(g))
+    back.policy_net, back.value_net = P, V
+    rest = ("genmove w", "move_history", "genmove b", "undo", "final_score", "showboard")
+    want = [g.send(c) for c in rest]
+    assert [twin.send(c) for c in rest] == want
+    assert [back.send(c) for c in rest] == want
+    assert back._komi == 6.5 and twin._move_history == g._move_history

@@ -38,6 +38,36 @@ static bool step(bk_pool* pool, long& steps, long& rows) {
     return true;
 }
 
+// the same fake networks behind the bk_evaluator callbacks of the C step loop (bk_pools_run), the batch "evaluated" by ANOTHER
+// thread between submit and wait -- as the GPU does for the engine's evaluator
+struct AsyncEval {
+    std::thread worker;
+    int64_t next = 1;
+};
+static void fill(const bk_pos* recs, int n, int npol, float* probs, float* values) {
+    for (int r = 0; r < npol; ++r) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+        for (int k = 0; k < 81; ++k) probs[(size_t)r * 81 + k] = 1.f + (float)((b[k] * 7 + k * 13 + r) % 17);   // not normalised: the loop does that
+    }
+    for (int r = 0; r < n; ++r) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&recs[r]);
+        unsigned h = 0;
+        for (int k = 0; k < 96; ++k) h = h * 31 + b[k];
+        values[r] = (float)(h % 2001) / 1000.f - 1.f;
+    }
+}
+static int64_t ev_submit(void* ctx, const bk_pos* recs, int n, int npol, float* probs, float* values) {
+    AsyncEval* e = static_cast<AsyncEval*>(ctx);
+    if (e->worker.joinable()) e->worker.join();           // (one batch in flight at a time is enough here)
+    e->worker = std::thread(fill, recs, n, npol, probs, values);
+    return e->next++;
+}
+static int ev_wait(void* ctx, int64_t) {
+    AsyncEval* e = static_cast<AsyncEval*>(ctx);
+    if (e->worker.joinable()) e->worker.join();
+    return 0;
+}
+
 int main(int argc, char** argv) {
     bk_search_params prm;
     bk_search_params_default(&prm);
@@ -88,6 +118,30 @@ int main(int argc, char** argv) {
         bk_pool_destroy(pools[p]);
     }
     std::printf("tsan_pool: %ld steps, %ld rows, %ld plies\n", steps, rows, plies);
+    // the step loop in C over three pools, batches completed by another thread; then a game carried to another pool by a snapshot
+    {
+        bk_pool* run[3];
+        for (int p = 0; p < 3; ++p) {
+            for (int g = 0; g < G; ++g) seeds[g] = 40260 + 3 * g + p;
+            run[p] = bk_pool_create(G, &prm, seeds.data(), threads);
+            if (!run[p]) return 2;
+            if (p == 1) bk_pool_set_dedup(run[p], 1);
+        }
+        AsyncEval ae;
+        bk_evaluator ev{&ae, ev_submit, ev_wait};
+        bk_run_info info;
+        if (bk_pools_run(run, 3, &ev, CAP, &info)) return 3;
+        std::vector<unsigned char> snap((size_t)bk_pool_snapshot(run[0], 0, nullptr, 0));
+        if (bk_pool_snapshot(run[0], 0, snap.data(), (long)snap.size()) != (long)snap.size()) return 4;
+        if (bk_pool_restore(run[2], 1, snap.data(), (long)snap.size())) return 5;
+        bk_game_stats a, b;
+        bk_pool_game_stats(run[0], 0, &a);
+        bk_pool_game_stats(run[2], 1, &b);
+        if (std::memcmp(&a, &b, sizeof a)) return 6;
+        for (int p = 0; p < 3; ++p) bk_pool_destroy(run[p]);
+        std::printf("tsan_pool: bk_pools_run: %llu steps, %llu rows; snapshot %zu bytes\n", (unsigned long long)info.steps,
+                    (unsigned long long)info.rows, snap.size());
+    }
     int rc = bk_team_selftest(4, 20000);
     int rc2[2] = {0, 0};
     {
