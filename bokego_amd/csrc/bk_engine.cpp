@@ -653,8 +653,7 @@ int enqueue(bk_engine* e, const void* d_feats, int dtype, int B, int n_policy, i
     // "cooperative form").  A workgroup that gives up waiting for its peers raises word 1 of the slot's flag block, which
     // travels to the host with the outputs: bk_wait then redoes the request with the one-CU form.
     const bool coop_ok = allow_coop && whole && precision == BK_PRECISION_F32 && stream == e->stream && e->d_coop_xchg && d_flag && !e->plan.force_nb;
-    int coop_form = coop_ok ? bk_coop_slices(a.B_policy + a.B_value, e->n_cu, e->plan) : 0;
-    if (coop_ok && !coop_form) coop_form = bk_coop3_form(a.B_policy, a.B_value, e->n_cu, e->plan);   // three boards on 2 / 4 CUs
+    const int coop_form = coop_ok ? bk_coop_form(a.B_policy, a.B_value, e->n_cu, e->plan) : 0;   // 2..12 CUs per board, or three boards on 2 / 4 / 8
     if (const int slices = coop_form) {
         a.coop_xchg = e->d_coop_xchg;
         a.coop_sync = e->d_coop_sync;
@@ -1189,8 +1188,7 @@ int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int* board
     if (n_policy < 0 || n_value < 0 || n_cu <= 0 || (precision != BK_PRECISION_F32 && precision != BK_PRECISION_F16X2)) return BK_ERR_ARG;
     if (boards_per_workgroup) *boards_per_workgroup = bk_pick_nb(n_policy, n_value, n_cu, precision);
     if (precision != BK_PRECISION_F32) return 0;
-    if (const int slices = bk_coop_slices(n_policy + n_value, n_cu)) return slices;
-    return bk_coop3_form(n_policy, n_value, n_cu);      // BK_COOP3_FORM_2 / _4 (102 / 104): three boards on 2 / 4 CUs
+    return bk_coop_form(n_policy, n_value, n_cu);       // 2..12, or BK_COOP3_FORM_2 / _4 / _8 (102 / 104 / 108): three boards on 2 / 4 / 8 CUs
 }
 
 int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* executed_mfma_flop, double* algorithmic_flop,
@@ -1201,10 +1199,11 @@ int bk_plan_flops(int n_policy, int n_value, int n_cu, int cooperative, double* 
     double exe = 0.0;
     int launches = 0;
     if (n_policy + n_value > 0) {
-        if (const int slices = cooperative ? bk_coop_slices(n_policy + n_value, n_cu) : 0) {
-            exe = bk_coop_mfma_flop_per_task(slices) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
+        const int form = cooperative ? bk_coop_form(n_policy, n_value, n_cu) : 0;
+        if (form > 0 && form < 100) {
+            exe = bk_coop_mfma_flop_per_task(form) * (n_policy + n_value);   // the one-board tile set, dealt out to the slices
             launches = 1;
-        } else if (cooperative && bk_coop3_form(n_policy, n_value, n_cu)) {
+        } else if (form >= 100) {
             exe = bk_mfma_flop_per_workgroup(3) * ((n_policy + 2) / 3 + (n_value + 2) / 3);   // the 3-board tile set, shared by 2 / 4 CUs
             launches = 1;
         } else {

@@ -109,10 +109,16 @@ int bk_coop_slices(int tasks, int n_cu, const bk_plan_opts& o = bk_plan_opts());
 // three boards of one net on 2 / 4 CUs (bk_kernels.hip, bk_leaf_eval_coop3_kernel): form codes beside the one-board form's 2..12
 #define BK_COOP3_FORM_2 102
 #define BK_COOP3_FORM_4 104
+#define BK_COOP3_FORM_8 108                           // three boards on EIGHT CUs: 81..96 tasks, at most 32 groups (32 x 8 CUs = the chip)
+#define BK_COOP3_FORM_8_MIN 81
+#define BK_COOP3_FORM_8_MAX 96
+#define BK_COOP3_FORM_8_MAX_GROUPS 32
+#define BK_COOP3_FORM_8_DEFAULT 1                     // 1: the planner picks it by itself in its range (else only option coop3 = 8)
 #define BK_COOP3_MAX_GROUPS 128                       // 128 groups x 2 CUs = the chip
 #define BK_COOP3_FORM_4_MAX 192                       // tasks: up to here four CUs per three boards ...
 #define BK_COOP3_FORM_2_MAX 384                       // ... and two up to here (beyond: whole-board workgroups)
 #define BK_COOP_XCHG_BYTES ((size_t)BK_COOP3_MAX_GROUPS * 2 * 243 * 128 * 4)   // the exchange buffer serves both forms
 int bk_coop3_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o = bk_plan_opts());   // 0 / BK_COOP3_FORM_2 / BK_COOP3_FORM_4
+int bk_coop_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o = bk_plan_opts());   // any of the above, or 0
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream);
 hipError_t bk_launch_leaf_eval_f16(const bk_eval_args& a, int nb, hipStream_t stream);

@@ -64,8 +64,17 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
         if (a.stamps && lane == 0 && wave < 4) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (k)] = _t; \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+// the clock into a variable (packed differences go into a free slot: stage_input)
+#define STAMP_T(var)                                                                               \
+    unsigned long long var;                                                                        \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define STAMP_T(var) do {} while (0)
 #endif
 
 namespace {
@@ -507,25 +516,34 @@ __device__ __forceinline__ void stage_input(const bk_eval_args& a, char* actb, i
     using G = Geo<NB>;
     constexpr int PER = (NB * 2187 + THREADS - 1) / THREADS;
     const int n = nb * 2187;
+    // every load is issued unconditionally (from a clamped, always valid index) and selected afterwards: a load behind a per-lane
+    // condition waits for its data where the branches join, i.e. the loads went out ONE AT A TIME -- ~800 cycles each, 26 per thread
+    // in a 256-thread three-board workgroup: 21 k cycles = 9 us of a 160-us request (in-kernel stamps, round 5)
     float v[PER];
     if (a.feats_dtype == BK_FEATS_F32_) {
         const float* X = static_cast<const float*>(a.feats) + (size_t)b0 * 2187;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = tid + THREADS * k;
-            v[k] = e < n ? __builtin_nontemporal_load(X + e) : 0.f;
+            v[k] = __builtin_nontemporal_load(X + (e < n ? e : 0));
         }
     } else {
         const uint8_t* X = static_cast<const uint8_t*>(a.feats) + (size_t)b0 * 2187;
+        uint8_t raw[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = tid + THREADS * k;
-            v[k] = e < n ? (float)__builtin_nontemporal_load(X + e) : 0.f;
+            raw[k] = __builtin_nontemporal_load(X + (e < n ? e : 0));
         }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = (float)raw[k];
     }
+    STAMP_T(t_issued);                                  // (diagnostic builds: loads issued / LDS zeroed / barrier passed / scattered)
     // zero the layer-0 region (halo!) while the loads fly
     for (int i = tid; i < G::L0_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    STAMP_T(t_zeroed);
     __syncthreads();
+    STAMP_T(t_barrier);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int e = tid + THREADS * k;
@@ -534,6 +552,12 @@ __device__ __forceinline__ void stage_input(const bk_eval_args& a, char* actb, i
             *reinterpret_cast<float*>(actb + G::addr0(b, y, x) + in_slot(c) * 4) = v[k];
         }
     }
+    STAMP_T(t_scattered);
+#ifdef BK_STAMPS
+    if (a.stamps && (tid & 63) == 0 && (tid >> 6) < 4)   // slot 31: the three phases' cycles, 16 bits each
+        a.stamps[((size_t)blockIdx.x * 4 + (tid >> 6)) * 32 + 31] = ((t_zeroed - t_issued) & 0xffff) | (((t_barrier - t_zeroed) & 0xffff) << 16) |
+                                                                   (((t_scattered - t_barrier) & 0xffff) << 32);
+#endif
 }
 
 // ---- heads of one board (one wave): untied-bias 1x1 conv, then softmax (PolicyNet) or the value MLP + tanh ----
@@ -976,7 +1000,7 @@ hipError_t launch_coop(const bk_eval_args& a, hipStream_t stream) {
 template <int SC>
 struct Coop3Tiles {
     static_assert(SC == 2 || SC == 4, "three boards on two or four CUs");
-    static constexpr int S = SC, WM = 2, RT = 8, CTW = 1;
+    static constexpr int S = SC, WM = 2, RT = 8, CTW = 1, TB = 0;
     static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = WM * CT, THREADS = 64 * NW;
     static constexpr int A0 = 1, A1 = 6, X0 = 0, X1 = -1, Y0a = 6, Y0b = 8, Y1 = -1;   // as Tiles<3>
@@ -985,25 +1009,34 @@ struct Coop3Tiles {
     static constexpr int XCHG_FLOATS = 2 * 243 * 128;   // per group: two layer parities
 };
 static_assert(Coop3Tiles<2>::XCHG_FLOATS * 4 * BK_COOP3_MAX_GROUPS <= BK_COOP_XCHG_BYTES, "exchange buffer");
+// Three boards on EIGHT CUs (round 5; 81..96 tasks = up to 32 groups x 8 CUs: every CU of the chip busy, where the 2-CUs-per-
+// board form of the one-board tile set leaves a quarter of them idle): a workgroup computes ONE 16-cout tile of all 243 points.
+// With one cout tile the two position groups would be two waves of eight tiles on two of the four SIMDs, so each group's tiles
+// [x-edge | 5 interior | y-edge a | y-edge b] are split between two waves: half 0 = [x-edge | 3 interior] (6 + 27 = 33 tile-taps
+// per 3x3 layer), half 1 = [2 interior | y-edge a | y-edge b] (18 + 12 = 30): four waves, one per SIMD.  The halves are two
+// tile-class layouts, i.e. two instantiations of conv_layer; a wave runs the one that belongs to it (wave-uniform).
+template <int H>
+struct Coop3Tiles8 {
+    static constexpr int S = 8, WM = 2, RT = 4, CTW = 1, TB = 4 * H, CT = 1;
+    static constexpr int NW = 4, THREADS = 64 * NW;
+    static constexpr int A0 = H == 0 ? 1 : 0, A1 = H == 0 ? 4 : 2, X0 = H == 0 ? 0 : -1, X1 = -1;
+    static constexpr int Y0a = H == 0 ? -1 : 2, Y0b = H == 0 ? -1 : 4, Y1 = -1;
+    static constexpr bool WM_EDGES = true, DB2 = true;
+    static constexpr int RING = 4;
+    static constexpr int XCHG_FLOATS = 2 * 243 * 128;
+};
 
-template <int SC>
-__global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_kernel(const bk_eval_args a) {
+// the body of the three-boards kernels for one wave's tile set F: the wave is (position group wm, cout tile wn of 8) of slice
+// sc of group grp; `dead` is the workgroup's "a poll ran out" word.  Every wave of a workgroup runs the same sequence of
+// barriers, whichever F it instantiates.
+template <class F>
+__device__ __forceinline__ void coop3_body(const bk_eval_args& a, char* smem, int* dead, int tid, int lane, int wave, int wm, int wn,
+                                           int sc, int grp) {
     using G = Geo<3>;
-    using F = Coop3Tiles<SC>;
     constexpr int THREADS = F::THREADS, RT = F::RT, S = F::S;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* actb = smem;
     const int dummy_byte = G::L3_BYTES;
     float* hs = reinterpret_cast<float*>(smem + G::L3_BYTES) + G::DUMMY_FLOATS;
-    __shared__ int dead;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    // blocks x + 8 (S j + s) are the S slices of group 8 j + x: one XCD, one L2 (see the one-board form)
-    const int sc = (bid >> 3) % S, grp = ((bid >> 3) / S) * 8 + (bid & 7);
-    if (grp >= a.tasks_p + a.tasks_v) return;           // the grid is padded to whole sets of 8 groups
     const int net = grp >= a.tasks_p;
     const bk_net_params& P = a.net[net];
     const int b0 = (net ? a.off_v + (grp - a.tasks_p) * 3 : a.off_p + grp * 3);
@@ -1011,7 +1044,6 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
     float* xb = a.coop_xchg + (size_t)grp * F::XCHG_FLOATS;
     unsigned int* cnt = a.coop_sync + grp * BK_COOP_SYNC_STRIDE;
 
-    const int wm = wave / F::CT, wn = sc * F::CT + (wave - wm * F::CT);   // position group; this wave's cout tile (of 8)
     f32x4 Wr[F::RING][1];
     {
         const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.wfrag + wn * 256), 0, 0x7ffffff0, 0x00020000);
@@ -1022,10 +1054,12 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
     if (tid == 0) {
         const bool poisoned = __hip_atomic_load(a.coop_sync + BK_COOP_POISON_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (poisoned) __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        dead = poisoned;
+        *dead = poisoned;
     }
+    STAMP(0);
     stage_input<3, THREADS>(a, actb, b0, nb, tid);
     __syncthreads();
+    STAMP(1);
 
     const int kq = lane >> 4;
     f32x4 acc[1][RT];
@@ -1034,19 +1068,20 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
     int xoff[RT];
     const int store_c = RP3 + REC3 - kq * 16 + (16 * wn + 4 * kq) * 4;
     f32x4 bv[1];
-    const int row_i = wm * RT * 16 + (lane & 15);
+    const int row_i = (wm * 8 + F::TB) * 16 + (lane & 15);      // this wave's first tile in the 3-board row table
     {
         lds_cchar* ap0[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) ap0[rt] = (lds_cchar*)actb + (g_rows<3>.a0[row_i + rt * 16] + kq * 16);
         conv_layer<F, true>(actb, P.wfrag, acc, lane, wm, wn, ap0, Wr);
+        STAMP(2);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int e = g_rows<3>.a3v[row_i + rt * 16];
         ap3[rt] = (lds_cchar*)actb + ((e & ~1) + kq * 16);
         valid |= (unsigned)(e & 1) << rt;
-        const TileRow fr = tile_row<3>(wm, rt, lane & 15);
+        const TileRow fr = tile_row<3>(wm, F::TB + rt, lane & 15);
         xoff[rt] = fr.valid ? (81 * fr.b + 9 * fr.y + fr.x) * 128 + 16 * wn + 4 * kq : -1;
     }
     load_bias<F>(bv, P.bias, wn, kq);
@@ -1074,6 +1109,7 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
             if (xoff[rt] >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xr, xoff[rt] * 4, par, SC1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(3 + 4 * L);
         __syncthreads();
         const bool last = L == 6;
 #ifdef BK_TEST_HOOKS
@@ -1081,7 +1117,7 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
 #endif
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!(last && sc != 0) && !dead) {
+            if (!(last && sc != 0) && !*dead) {
                 const unsigned int target = (unsigned int)S * (L + 1);
                 int spins = 0;
 #pragma unroll 1
@@ -1090,7 +1126,7 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
                     if (++spins > COOP_SPIN_LIMIT) {
                         __hip_atomic_store(a.coop_err, a.coop_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(a.coop_sync + BK_COOP_POISON_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dead = 1;
+                        *dead = 1;
                         break;
                     }
                 }
@@ -1098,8 +1134,12 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
         }
         if (last && sc != 0) return false;              // uniform over the workgroup
         __syncthreads();
-        // the peers' channels: chunk j = (point q, foreign 16-byte channel chunk cf), eight in flight per thread
-        constexpr int OWN = 32 / SC, FC = 32 - OWN, N = 243 * FC, PER = (N + THREADS - 1) / THREADS, BATCH = SC == 4 ? 12 : 8;
+        STAMP(4 + 4 * L);
+        // the peers' channels: chunk j = (point q, foreign 16-byte channel chunk cf), BATCH in flight per thread
+        constexpr int OWN = 32 / S, FC = 32 - OWN, N = 243 * FC, PER = (N + THREADS - 1) / THREADS;
+        // loads in flight per thread: all of them where the registers are there -- the 256-thread form (S == 8: one wave per SIMD, 27
+        // chunks per thread) fetched in three rounds of 12 and spent 10.8 k cycles per layer on 106 KB, the 512-thread forms 5.2 k
+        constexpr int BATCH = S == 2 ? 8 : S == 4 ? 12 : PER;
 #pragma unroll 1
         for (int k0 = 0; k0 < PER; k0 += BATCH) {
             f32x4 v[BATCH];
@@ -1122,6 +1162,7 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
             }
         }
         __syncthreads();
+        STAMP(5 + 4 * L);
         return true;
     };
 
@@ -1129,12 +1170,37 @@ __global__ void __launch_bounds__((Coop3Tiles<SC>::THREADS)) bk_leaf_eval_coop3_
 #pragma unroll 1
     for (int L = 1; L < 7; ++L) {
         conv_layer<F, false>(actb, P.wfrag + BK_L0_FLOATS + (L - 1) * BK_L3_FLOATS, acc, lane, wm, wn, ap3, Wr);
+        STAMP(2 + 4 * L);
         load_bias<F>(bv, P.bias + L * 128, wn, kq);
         __syncthreads();
         if (!exchange(L)) return;
     }
     if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (wave < nb) run_heads<G>(a, P, actb, hs + wave * 96, net, lane, wave, b0 + wave);
+    STAMP(30);
+}
+
+template <int SC>
+__global__ void __launch_bounds__((SC == 8 ? Coop3Tiles8<0>::THREADS : Coop3Tiles<SC == 8 ? 4 : SC>::THREADS)) bk_leaf_eval_coop3_kernel(const bk_eval_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int dead;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    // blocks x + 8 (S j + s) are the S slices of group 8 j + x: one XCD, one L2 (see the one-board form)
+    const int sc = (bid >> 3) % SC, grp = ((bid >> 3) / SC) * 8 + (bid & 7);
+    if (grp >= a.tasks_p + a.tasks_v) return;           // the grid is padded to whole sets of 8 groups
+    if constexpr (SC == 8) {
+        // four waves = (position group, half of its tiles); the workgroup's one cout tile is its slice number
+        const int wm = wave >> 1;
+        if (wave & 1) coop3_body<Coop3Tiles8<1>>(a, smem, &dead, tid, lane, wave, wm, sc, sc, grp);
+        else coop3_body<Coop3Tiles8<0>>(a, smem, &dead, tid, lane, wave, wm, sc, sc, grp);
+    } else {
+        using F = Coop3Tiles<SC == 8 ? 4 : SC>;
+        const int wm = wave / F::CT, wn = sc * F::CT + (wave - wm * F::CT);   // position group; this wave's cout tile (of 8)
+        coop3_body<F>(a, smem, &dead, tid, lane, wave, wm, wn, sc, grp);
+    }
 }
 
 template <int SC>
@@ -1143,6 +1209,7 @@ hipError_t launch_coop3(const bk_eval_args& a, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     auto kern = bk_leaf_eval_coop3_kernel<SC>;
+    constexpr int THREADS = SC == 8 ? Coop3Tiles8<0>::THREADS : Coop3Tiles<SC == 8 ? 4 : SC>::THREADS;
     if (!attr_set_dev[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1153,9 +1220,9 @@ hipError_t launch_coop3(const bk_eval_args& a, hipStream_t stream) {
     args.tasks_v = (a.B_value - a.off_v + 2) / 3;
     const int groups = args.tasks_p + args.tasks_v;
     if (groups == 0) return hipSuccess;
-    if (groups > BK_COOP3_MAX_GROUPS) return hipErrorInvalidValue;
+    if (groups > BK_COOP3_MAX_GROUPS || (SC == 8 && groups > BK_COOP3_FORM_8_MAX_GROUPS)) return hipErrorInvalidValue;
     const int grid = (groups + 7) / 8 * 8 * SC;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Coop3Tiles<SC>::THREADS), Geo<3>::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), Geo<3>::LDS_BYTES, stream, args);
     return hipGetLastError();
 }
 
@@ -1192,6 +1259,8 @@ constexpr long tile_taps(int kw) {
     return (long)(F::A1 - F::A0) * taps + (long)(nx + ny) * (taps - skip);
 }
 static_assert(tile_taps<Tiles<3>>(3) == 63 && tile_taps<Tiles<3>>(5) == 170, "3 boards: 63 of 72 / 170 of 200 tile-taps");
+static_assert(tile_taps<Coop3Tiles8<0>>(3) == 33 && tile_taps<Coop3Tiles8<1>>(3) == 30 && tile_taps<Coop3Tiles8<0>>(3) + tile_taps<Coop3Tiles8<1>>(3) == tile_taps<Tiles<3>>(3),
+              "three boards on eight CUs: the two halves of a position group's tiles, 33 + 30 = 63 tile-taps");
 static_assert(tile_taps<Tiles<2>>(3) == 87 && tile_taps<Tiles<1>>(3) == 48 && tile_taps<Tiles<1>>(5) == 130, "2 boards: 87 of 99; 1 board: 48 of 54");
 // FLOP the matrix unit executes for ONE net on one NB-board workgroup: per (tile, tap) 7 k-steps in layer 0 (28 input
 // slots) resp. 32 in a 3x3 layer, x 8 cout tiles, of v_mfma_f32_16x16x4_f32 (2 * 16 * 16 * 4 = 2,048 FLOP each)
@@ -1271,11 +1340,23 @@ int bk_coop3_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o) {
         const int v = o.coop3;
         if (v == 0) return 0;
         if ((v == 2 || v == 4) && per_xcd * v <= cus) return v == 2 ? BK_COOP3_FORM_2 : BK_COOP3_FORM_4;
+        if (v == 8 && per_xcd * 8 <= cus && groups <= BK_COOP3_FORM_8_MAX_GROUPS) return BK_COOP3_FORM_8;
     }
     // measured (tools/coop_probe.py): see DESIGN 3
+    if (tasks >= BK_COOP3_FORM_8_MIN && tasks <= BK_COOP3_FORM_8_MAX && groups <= BK_COOP3_FORM_8_MAX_GROUPS && per_xcd * 8 <= cus && BK_COOP3_FORM_8_DEFAULT)
+        return BK_COOP3_FORM_8;
     if (tasks > BK_COOP_MAX_TASKS && tasks <= BK_COOP3_FORM_4_MAX && per_xcd * 4 <= cus) return BK_COOP3_FORM_4;
     if (tasks > n_cu && tasks <= BK_COOP3_FORM_2_MAX && per_xcd * 2 <= cus) return BK_COOP3_FORM_2;
     return 0;
+}
+
+// the cooperative form of a request, if any: the three-boards-on-eight-CUs form where it applies (in its range it replaces the
+// 2-CUs-per-board form), else 2..12 CUs per board by task count, else three boards on 4 / 2 CUs; 0: whole-board workgroups
+int bk_coop_form(int B_policy, int B_value, int n_cu, const bk_plan_opts& o) {
+    const int f3 = bk_coop3_form(B_policy, B_value, n_cu, o);
+    if (f3 == BK_COOP3_FORM_8 && o.coop < 0) return f3;     // (a forced number of CUs per board goes first)
+    const int slices = bk_coop_slices(B_policy + B_value, n_cu, o);
+    return slices ? slices : f3;
 }
 
 hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream_t stream) {
@@ -1283,6 +1364,7 @@ hipError_t bk_launch_leaf_eval_coop(const bk_eval_args& a, int slices, hipStream
     // 8 slices: 6 row groups 86, 3: 84;  2 slices: 2 row groups 189 / 194, 3: 200 / 204.  Every wave arriving and polling
     // for itself (no workgroup barriers around the meeting point): 177 at 63 tasks -- four times the pollers on the counters
     switch (slices) {
+        case BK_COOP3_FORM_8: return launch_coop3<8>(a, stream);   // three boards on eight CUs
         case BK_COOP3_FORM_2: return launch_coop3<2>(a, stream);   // three boards on two CUs
         case BK_COOP3_FORM_4: return launch_coop3<4>(a, stream);   // three boards on four CUs
         case 12: return launch_coop<4, 3, 2>(a, stream);  // 4 cout ranges x 3 point ranges: 4 waves x 1 tile

@@ -193,7 +193,10 @@ def test_launch_planner_choices(lib, monkeypatch):
     nb = ctypes.c_int(0)
     q = lambda npol, nval, prec=0, n_cu=256: lib.bk_plan_query(npol, nval, n_cu, prec, ctypes.byref(nb))  # noqa: E731
     assert [q(1, 1), q(1, 7), q(1, 8), q(1, 31), q(1, 32), q(1, 39), q(1, 40), q(1, 63), q(1, 64), q(1, 79), q(1, 80), q(0, 128),
-            q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 2, 2, 0]
+            q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 108, 2, 0]
+    # 81..96 tasks in at most 32 groups of three boards of one net: three boards on EIGHT CUs (code 108; round 5: 140 us against
+    # the 2-CUs-per-board form's 174); one group too many, or one task, and the 2-CUs-per-board form runs
+    assert [q(0, 81), q(3, 93), q(0, 96), q(6, 90), q(1, 95), q(4, 92), q(0, 97), q(1, 79)] == [108, 108, 108, 108, 2, 2, 2, 3]
     # between the whole-board forms' ranges: three boards of one net on 4 CUs (code 104: 129..192 tasks, while the groups
     # of three fit 8 to an XCD) and on 2 CUs (102: 257..384 tasks, 16 groups to an XCD)
     assert [q(1, 128), q(2, 150), q(6, 186), q(1, 190), q(1, 191), q(8, 200), q(0, 256), q(1, 256), q(20, 300), q(30, 340), q(3, 381),

@@ -134,6 +134,17 @@ def test_three_boards_form_falls_back_when_a_peer_never_arrives():
     assert eng.stats()["coop_fallbacks"] == 2
     for k in good:
         assert np.array_equal(ref[(150, 2)][k], bad[0][k]) and np.array_equal(ref[(340, 30)][k], bad[1][k]) and np.array_equal(ref[(340, 30)][k], good[k]), k
+    # three boards on eight CUs (forced): the same fallback
+    with eng.options(coop=0):
+        ref8 = eng.eval(x[:88], logits=True, probs=True, value=True, n_policy=2)
+    eng.set_option("coop3", 8)
+    eng.set_option("coop_fault", 1)
+    bad8 = eng.eval(x[:88], logits=True, probs=True, value=True, n_policy=2)
+    eng.set_option("coop_fault", 0)
+    assert eng.stats()["coop_fallbacks"] == 3
+    good8 = eng.eval(x[:88], logits=True, probs=True, value=True, n_policy=2)
+    assert eng.stats()["coop_fallbacks"] == 3
+    assert all(np.array_equal(ref8[k], bad8[k]) and np.array_equal(ref8[k], good8[k]) for k in ref8)
     eng.close()
 
 

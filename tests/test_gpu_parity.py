@@ -541,6 +541,24 @@ def test_three_boards_on_two_or_four_cus_give_the_same_bits(monkeypatch):
                 assert np.array_equal(want[k], got[k]), (mode, B, npol, k)
         assert eng.stats()["coop_launches"] - c0 == (10 if mode != "4" else 5), mode
     assert eng.stats()["coop_fallbacks"] == 0
+    # round 5: three boards on EIGHT CUs (one 16-cout tile of all 243 points per workgroup, four waves of four tiles): up to 32
+    # groups, i.e. 96 tasks; forced here over its whole range and below it -- the same bits as the whole-board forms
+    small = ((1, 1), (5, 2), (31, 0), (60, 30), (80, 1), (84, 0), (88, 2), (93, 3), (96, 0))
+    eng.set_option("coop", 0)
+    ref8 = [eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol) for B, npol in small]
+    eng.set_option("coop", -1)
+    eng.set_option("coop3", 8)
+    c0 = eng.stats()["coop_launches"]
+    for (B, npol), want in zip(small, ref8):
+        got = eng.eval(x[:B], logits=True, probs=True, value=True, n_policy=npol)
+        for k in want:
+            assert np.array_equal(want[k], got[k]), ("8", B, npol, k)
+    assert eng.stats()["coop_launches"] - c0 == len(small) and eng.stats()["coop_fallbacks"] == 0
+    got = eng.eval(x[:95], logits=True, probs=True, value=True, n_policy=1)       # 1 + 32 groups: does not fit, the usual forms run
+    with eng.options(coop=0):
+        plain = eng.eval(x[:95], logits=True, probs=True, value=True, n_policy=1)
+    assert all(np.array_equal(got[k], plain[k]) for k in got)
+    eng.set_option("coop3", -1)
     eng.close()
 
 

@@ -16,10 +16,10 @@ selfplay.self_play(ev, n_games=64, rollouts=50, cap=8192)
 ref = {}
 if "--fine" in sys.argv:
     out = []
-    for spec in (0, 60, 65, 70, 75, 80, 90):
-        for rows in (4, 8, 12):
-            for tc in (112, 120, 124, 128):
-                if spec == 0 and (rows != 8 or tc != 128):
+    for spec in (0, 60, 70, 80, 90):
+        for rows in (4, 8):
+            for tc in (88, 92, 96, 100, 112, 128, 0):
+                if spec == 0 and rows != 8:
                     continue
                 best = None
                 for _ in range(3):
