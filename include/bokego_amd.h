@@ -213,7 +213,7 @@ int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every 
  * BK_ENCODE_OVERLAP, BK_ROCTX); no request ever looks at the environment, and a live engine is changed through this call
  * only.  Results never depend on any of them (every launch form is bit-identical); they exist so that tests and probes can
  * force each form.  Names: "force_nb" (0 | 1..3 boards per workgroup), "no_split", "coop" (-1 by task count | 0 off | 2, 3,
- * 4, 6, 8, 12 CUs per board), "coop3" (-1 | 0 | 2 | 4), "no_direct", "no_head_part", "copy_threads", "encode_overlap".
+ * 4, 6, 8, 12 CUs per board), "coop3" (-1 | 0 | 2 | 4 | 8), "no_direct", "no_head_part", "copy_threads", "encode_overlap".
  * Unknown name: BK_ERR_ARG.  Builds with -DBK_TEST_HOOKS (bk_has_test_hooks() == 1; never shipped as libbokego_amd.so) add
  * "coop_fault" and "fault_submit" (fault injection for tests/test_gpu_hooks.py).
  */
@@ -235,8 +235,8 @@ int bk_engine_max_batch(bk_engine *e);
 /*
  * Launch planner, as a pure function (no engine, no GPU): how a request of n_policy PolicyNet rows + n_value ValueNet
  * rows would be launched on a device with n_cu compute units at `precision`.  Returns the CUs per board of the
- * cooperative small-batch form (12/8/6/4/3/2; ticket path, fp32 only), 104 / 102 for groups of three boards shared by 4 / 2
- * CUs (requests of 129..192 / 257..384 tasks), or 0 when the ordinary form runs;
+ * cooperative small-batch form (12/8/6/4/3/2; ticket path, fp32 only), 108 / 104 / 102 for groups of three boards shared by 8 / 4 /
+ * 2 CUs (requests of 81..96 tasks in at most 32 groups / 129..192 / 257..384 tasks), or 0 when the ordinary form runs;
  * *boards_per_workgroup (may be NULL) receives the ordinary form's workgroup size (1..3) for a single launch.
  */
 int bk_plan_query(int n_policy, int n_value, int n_cu, int precision, int *boards_per_workgroup);
