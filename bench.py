@@ -933,7 +933,13 @@ def main():
         if not threads:
             share = max(1, min(16, (cpu_quota() or len(os.sched_getaffinity(0))) // world))
             threads = max(1, share - 4 if share > 8 else share - 1)      # as launch_plan: room for the HIP runtime's thread
-        threads = max(1, min(12, threads, (args.selfplay_games // world) // 16 or 1))    # <= one per 8 games of a pool (two pools): selfplay.default_threads
+        host_threads = threads                                          # what this rank may use at all
+
+        def threads_for(games_here):
+            """<= one host thread per 8 games of a pool (two pools): selfplay.default_threads; the weak leg's 512 games per rank
+            take more than the strong leg's 512 / n_gpus"""
+            return max(1, min(12, host_threads, games_here // 16 or 1))
+        threads = threads_for(args.selfplay_games // world)
         sp = {"config": f"configs[3]: {args.selfplay_games} games, 400 rollouts/move, games sharded gid % n_gpus",
               "collective": f"1 all-reduce of {selfplay.STATS_LEN} doubles per generation (scalars + first-move and root-visit histograms)",
               "host_threads_per_rank": threads, "step_loop": "C (bk_pools_run)" if selfplay.NATIVE_LOOP else "Python (run_pools)",
@@ -951,15 +957,15 @@ def main():
             all-reduce, and the visit / value statistics it sums"""
             ev = selfplay.EngineEvaluator(eng)
             barrier()
-            local, total = selfplay.self_play(ev, n_games=n_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads,
+            mine = len(selfplay.shard_game_ids(n_games, rank, world))
+            local, total = selfplay.self_play(ev, n_games=n_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads_for(mine),
                                               reduce_device=red)
             per_rank_s = gather(local["seconds"])
             reduce_ms = gather(local["allreduce_s"] * 1e3)
             secs = max(per_rank_s)
-            mine = len(selfplay.shard_game_ids(n_games, rank, world))
             return {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
                     "per_rank_seconds": per_rank_s, "per_rank_seconds_min": min(per_rank_s), "per_rank_seconds_max": secs,
-                    "games_per_rank": mine, "plies": total["plies"], "value_evals": total["value_evals"],
+                    "games_per_rank": mine, "host_threads": threads_for(mine), "plies": total["plies"], "value_evals": total["value_evals"],
                     "value_evals_per_s": total["value_evals"] / secs,
                     "children_evaluated_per_expansion": selfplay.default_eager_top(prec, mine),
                     "black_wins": total["black_wins"], "stats_allreduce_ms": max(reduce_ms), "stats_allreduce_ms_per_rank": reduce_ms,

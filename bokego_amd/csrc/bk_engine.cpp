@@ -82,7 +82,7 @@ constexpr double kBnEps = 1e-5;  // torch.nn.BatchNorm default, nnet.py:33,98-99
 // Staging of a large host buffer (the reference-shaped call: f32 planes, 35.8 MB at B = 4,096): a single memcpy into the
 // pinned slot runs at ~10 GB/s and the H2D copy only starts behind it -- 3.5 + 0.7 ms in front of an 8 ms kernel.  Here a
 // few worker threads copy the buffer slice by slice while the submitting thread enqueues each slice's H2D copy as soon as
-// that slice has landed, so staging costs about as long as the slower of the two (both ~0.7 ms).  BK_COPY_THREADS=0 turns it
+// that slice has landed, so staging costs about as long as the slower of the two (both ~0.7 ms).  Option copy_threads = 0 (BK_COPY_THREADS at create) turns it
 // off.  Workers sleep on a condition variable between requests.
 class CopyPool {
 public:
@@ -901,7 +901,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
     // leaf kernel writes the flag word and the outputs (a few hundred bytes) into the pinned output block, which the host
     // reads after the request's event.  Two of the five enqueues and ~12 us of copy kernels per round trip disappear
     // (rocprofv3 timeline, profiles/r03_genmove_timeline.md).  fp32 only: the f16x2 kernel's overflow flag is raised with
-    // an atomic max, which is not used on host memory here.  BK_NO_DIRECT=1 restores the copies.
+    // an atomic max, which is not used on host memory here.  Option no_direct = 1 restores the copies.
     const bool direct = !chained && B > 0 && e->precision == BK_PRECISION_F32 && s->h_in_dev && s->h_out_dev && !e->no_direct;
     s->direct = direct;
     if (B > 0) {
@@ -950,7 +950,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
         // The encoder (13 us per 4,096 records) runs on the COMPUTE stream, in front of the request's leaf kernel.  Round 1
         // launched it on the copy-in stream so that it overlapped the previous request's leaf kernel; under that
         // kernel its workgroups wait for CUs, so it "ran" 110-370 us per call (6-8 % of the summed kernel time of a
-        // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  BK_ENCODE_OVERLAP=1 restores that.
+        // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  Option encode_overlap = 1 restores that.
         const bool enc_overlap = e->encode_overlap != 0;
         if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
             HIP_TRY(e, bk_launch_encode(direct ? s->h_in_dev : s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));

@@ -356,7 +356,7 @@ def test_random_weights_vs_oracle(gold, precision, seed, gain):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
-def test_split_launch_is_bit_identical(precision, monkeypatch):
+def test_split_launch_is_bit_identical(precision):
     """Mid-size batches run as whole rounds of 3-board workgroups + a tail launch with smaller workgroups
     (bk_stats().split_launches); every output must be bit-identical to the single-launch result."""
     from bokego_amd.engine import LeafEngine
@@ -422,8 +422,8 @@ def test_sweep_worst_cases_vs_reference(precision, wset):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
-def test_every_workgroup_size_gives_the_same_bits(precision, monkeypatch):
-    """1-, 2- and 3-board workgroups (BK_FORCE_NB) are three different code paths -- different tile sets, edge-class tap
+def test_every_workgroup_size_gives_the_same_bits(precision):
+    """1-, 2- and 3-board workgroups (option force_nb) are three different code paths -- different tile sets, edge-class tap
     skipping for 2 and 3 boards, different wave grids -- and must agree bit for bit on every output, for ragged batch
     sizes and policy prefixes."""
     from bokego_amd.engine import LeafEngine
@@ -449,10 +449,10 @@ def _small_batches(eng, x):
             for B, npol in ((1, 1), (1, 0), (2, 2), (5, 3), (9, 9), (16, 1), (31, 0), (40, 1), (62, 1), (63, 30), (64, 64), (100, 28), (128, 0))]
 
 
-def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
+def test_cooperative_small_batch_form_gives_the_same_bits():
     """Small fp32 batches on the engine's stream run with 12 / 8 / 6 / 4 / 3 / 2 CUs per board (cooperative kernel: output
     channels split 8, 4 or 2 ways and / or the board's points split 3 ways;
-    bk_stats().coop_launches): every output bit-identical to the one-CU-per-board form (BK_COOP=0), for each slice
+    bk_stats().coop_launches): every output bit-identical to the one-CU-per-board form (option coop = 0), for each slice
     count forced over the whole range as well as for the engine's own choice, with no fallback taken."""
     from bokego_amd.engine import LeafEngine
     from bokego_amd.workload import make_batch
@@ -484,7 +484,7 @@ def test_cooperative_small_batch_form_gives_the_same_bits(monkeypatch):
     eng.close()
 
 
-def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
+def test_cooperative_form_repeats_exactly_under_load():
     """The meeting points of the cooperative kernel hold under repetition and with a second engine's large launches
     competing for the CUs from another stream: 300 small evaluations of varying size, every one equal to the first
     answer for its size."""
@@ -513,7 +513,7 @@ def test_cooperative_form_repeats_exactly_under_load(monkeypatch):
     other.close()
 
 
-def test_three_boards_on_two_or_four_cus_give_the_same_bits(monkeypatch):
+def test_three_boards_on_two_or_four_cus_give_the_same_bits():
     """Requests between the whole-board forms' ranges (129..192 and 257..384 tasks) run as groups of three boards of one net
     shared by 4 resp. 2 CUs (bk_leaf_eval_coop3_kernel: output channels split, the 3-board tile set, the cooperative
     exchange): every output bit-identical to the whole-board forms (BK_COOP3=0), partial groups, policy rows and both forced
@@ -591,10 +591,10 @@ def test_f16x2_overflow_flags_are_per_call_across_caller_streams(weights, gold):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
-def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, monkeypatch, precision):
+def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, precision):
     """A large request of host planes is staged by a pool of copy threads and launched in two parts (the first 768
     positions run while the rest is still on its way: bk_engine.cpp submit_common).  Outputs are bit-identical to the
-    single-launch path (BK_NO_HEAD_PART, BK_COPY_THREADS=0) for f32 and u8 planes, whole batches and policy prefixes on
+    single-launch path (options no_head_part = 1, copy_threads = 0) for f32 and u8 planes, whole batches and policy prefixes on
     either side of the split, pipelined tickets included."""
     from bokego_amd.engine import LeafEngine
     from bokego_amd.workload import make_batch
@@ -625,9 +625,9 @@ def test_large_host_requests_launched_in_two_parts_give_the_same_bits(weights, m
     eng.close()
 
 
-def test_small_requests_without_copies_give_the_same_bits(weights, monkeypatch):
+def test_small_requests_without_copies_give_the_same_bits(weights):
     """Small fp32 requests skip both copies ("direct": the encoder reads position records from the pinned slot, the leaf
-    kernel writes flag + outputs into the pinned output block).  Same bits as with the copies (BK_NO_DIRECT), for position
+    kernel writes flag + outputs into the pinned output block).  Same bits as with the copies (option no_direct), for position
     records and for planes, cooperative and one-CU forms, back-to-back tickets; the f16x2 engine keeps its copies."""
     from bokego_amd import go
     from bokego_amd.engine import LeafEngine
