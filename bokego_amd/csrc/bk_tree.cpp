@@ -1418,7 +1418,7 @@ int bk_pool_game_moves(const bk_pool* p, int g, int16_t* out, int cap) {
     if (g < 0 || g >= (int)p->games.size()) return -1;
     const auto& m = p->games[g].moves;
     const int n = std::min((int)m.size(), cap);
-    std::memcpy(out, m.data(), (size_t)n * sizeof(int16_t));
+    if (n > 0) std::memcpy(out, m.data(), (size_t)n * sizeof(int16_t));   // (an empty vector's data() may be null)
     return (int)m.size();
 }
 
@@ -1751,6 +1751,14 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
         for (const auto& kv : *m)
             if (!node_ok(kv.first) || !all_ok(kv.second)) return false;
     if (gm.priors.size() % 81) return false;
+    for (int i = 0; i < n; ++i) {                        // the rules code indexes tables by stone colour, point and ko point
+        const bk_pos& q = gm.poses[(size_t)i];
+        for (int k = 0; k < 81; ++k)
+            if (q.board[k] != BK_EMPTY && q.board[k] != BK_BLACK && q.board[k] != BK_WHITE) return false;
+        if (q.ko < BK_NO_KO || q.ko > 80 || q.turn < 0 || q.turn > 100000) return false;
+        if (!(q.last_move == BK_NO_MOVE || q.last_move == BK_PASS || (q.last_move >= 0 && q.last_move <= 80))) return false;
+        if (gm.nodes[(size_t)i].mv != q.last_move) return false;      // intern(): a node is reached by its position's last move
+    }
     for (const TNode& nd : gm.nodes) {
         if (nd.n_kids < 0 || nd.kids_off < 0 || (size_t)nd.kids_off + (size_t)nd.n_kids > gm.kid_ids.size()) return false;
         if (nd.has_prior && (nd.prior_off < 0 || (size_t)nd.prior_off + 81 > gm.priors.size())) return false;

@@ -535,3 +535,61 @@ def test_the_default_launchers_tree_copies_and_pickles_with_its_protocol_state()
     assert [twin.send(c) for c in rest] == want
     assert [back.send(c) for c in rest] == want
     assert back._komi == 6.5 and twin._move_history == g._move_history
+
+
+def test_restore_refuses_or_survives_corrupted_snapshots():
+    """bk_pool_restore checks every index the search and the rules code would follow (node ids, edge and prior offsets, stone
+    colours, ko and move points): 4,000 random corruptions of a real mid-game snapshot -- byte flips, truncations, spliced
+    garbage -- are either refused (the game stays as it was) or restored into a state every read-only view can walk.  Memory
+    safety, not plausibility: `make check` runs this under AddressSanitizer + UBSan."""
+    f = FakeNets()
+    prm = selfplay.search_params(rollouts=40, expand_thresh=5, noise_weight=0.25, sample_plies=3, max_turns=12, prune=0, record_visits=1,
+                                 eager_top=4, speculate=3)
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    src = selfplay.GamePool([7], prm, cap=256, threads=1)
+    while src.info(0)["n_moves"] < 4:
+        feats, npol = src.collect()
+        src.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
+    good = src.snapshot(0)
+    dst = selfplay.GamePool([1], prm, cap=256, threads=1)
+    dst.restore(0, good)
+    before = (dst.moves(0), dst.info(0), dst.root_children(0))
+    rng = np.random.default_rng(3)
+    refused = accepted = 0
+    lib = dst._lib
+    ids, mv16, n32, v64 = np.empty(81, np.int32), np.empty(128, np.int16), np.empty(81, np.int32), np.empty(81, np.float64)
+    for trial in range(4000):
+        b = bytearray(good)
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            at = int(rng.integers(0, len(b) - 8))
+            b[at:at + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            at = int(rng.integers(16, len(b) - 4))
+            b[at:at + 4] = int(rng.integers(-2**31, 2**31)).to_bytes(4, "little", signed=True)
+        try:
+            dst.restore(0, bytes(b))
+        except ValueError:
+            refused += 1
+            assert (dst.moves(0), dst.info(0), dst.root_children(0)) == before      # a refused restore changes nothing
+            continue
+        accepted += 1
+        dst.info(0); dst.moves(0); dst.root_children(0); dst.game_stats(0)
+        for ply in range(len(dst.moves(0))):
+            try:
+                dst.visits(0, ply)
+            except IndexError:
+                pass
+        root = lib.bk_pool_root_id(dst._h, 0)
+        lib.bk_pool_node_children(dst._h, 0, root, ids.ctypes.data, 81)
+        lib.bk_pool_principal_variation(dst._h, 0, mv16.ctypes.data, 128)
+        lib.bk_pool_root_children(dst._h, 0, mv16.ctypes.data, n32.ctypes.data, v64.ctypes.data)
+        assert len(dst.snapshot(0)) > 0
+        dst.restore(0, good)
+        before = (dst.moves(0), dst.info(0), dst.root_children(0))
+    assert refused > 1500 and accepted > 200, (refused, accepted)
