@@ -839,7 +839,11 @@ def main():
                           "n_gpus": world, "rollouts_per_move": args.rollouts, "plies": total["plies"],
                           "leaf_evals": total["value_evals"], "leaf_evals_per_s_per_gpu": total["value_evals"] / secs / world,
                           "black_wins": total["black_wins"], "white_wins": total["white_wins"],
-                          "allreduce_ms": local["allreduce_s"] * 1e3, "mean_batch": ev.positions / max(1, ev.batches)}))
+                          "allreduce_ms": local["allreduce_s"] * 1e3, "mean_batch": ev.positions / max(1, ev.batches),
+                          # the visit / value statistics the all-reduce carries (STATS_FIELDS / STATS_HISTS)
+                          "n_root_values": total["n_root_values"], "mean_root_value": total["mean_root_value"],
+                          "mean_abs_root_value": total["mean_abs_root_value"], "root_visit_hist": total["root_visit_hist"],
+                          "first_move_hist": total["first_move_hist"]}))
     if args.out:
         write_records(os.path.join(args.out, f"rank{rank}"), local["games"], local["visits"])
     eng.close()
