@@ -1000,6 +1000,9 @@ def main():
         else:
             sp["weak"] = {"same_as": args.precision, "what": "one rank: the weak leg is the strong leg"}
         eng.set_precision(args.precision)
+        st = eng.stats()      # rank 0's engine over everything above: which launch forms ran, and whether anything had to be redone
+        sp["engine_counters_rank0"] = {k: st[k] for k in ("evals", "batches", "mean_batch", "positions_encoded", "split_launches", "coop_launches",
+                                                           "coop_fallbacks", "f16_overflow_fallbacks", "failed_submissions", "host_wait_ms_sum")}
         sp["games_per_min"] = sp[args.precision]["games_per_min"]
         sp["stats_allreduce_ms"] = sp[args.precision]["stats_allreduce_ms"]
 
