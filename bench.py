@@ -921,6 +921,18 @@ def main():
                 whole = kernel_us(B)
             coop = kernel_us(B)
             small[f"B{B}"] = {"whole_board_workgroups_us": whole[0], key: coop[0], "cooperative_launches": coop[1], "fallbacks": coop[2]}
+        # 81..96 tasks: three boards on EIGHT CUs (round 5) against the 2-CUs-per-board form it replaces there
+        with eng.options(coop3=0):
+            two = kernel_us(90)
+        eight = kernel_us(90)
+        small["B90"] = {"two_cus_per_board_us": two[0], "three_boards_on_8_cus_us": eight[0], "cooperative_launches": eight[1], "fallbacks": eight[2]}
+        # how far each of these requests is from the fp32-MFMA roof (B boards + 1 policy row = B + 2 network tasks of 133.4 MFLOP)
+        for k, v in small.items():
+            if k.startswith("B"):
+                tasks = int(k[1:]) + 2
+                best = min(t for n, t in v.items() if n.endswith("_us"))
+                v["tasks"] = tasks
+                v["frac_of_fp32_mfma_peak"] = tasks * FLOP_PER_LEAF / 2 / (best * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
 
     # Secondary measurement (outside the timed region above): BASELINE configs[3] -- 512 self-play games,
     # 400 rollouts/move, sharded over the ranks (gid % world), one all-reduce of the statistics at the end.
