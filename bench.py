@@ -926,10 +926,10 @@ def main():
             two = kernel_us(90)
         eight = kernel_us(90)
         small["B90"] = {"two_cus_per_board_us": two[0], "three_boards_on_8_cus_us": eight[0], "cooperative_launches": eight[1], "fallbacks": eight[2]}
-        # how far each of these requests is from the fp32-MFMA roof (B boards + 1 policy row = B + 2 network tasks of 133.4 MFLOP)
+        # how far each of these requests is from the fp32-MFMA roof (B ValueNet rows, the first of which also runs the PolicyNet: B + 1 network tasks of 133.4 MFLOP)
         for k, v in small.items():
             if k.startswith("B"):
-                tasks = int(k[1:]) + 2
+                tasks = int(k[1:]) + 1
                 best = min(t for n, t in v.items() if n.endswith("_us"))
                 v["tasks"] = tasks
                 v["frac_of_fp32_mfma_peak"] = tasks * FLOP_PER_LEAF / 2 / (best * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
