@@ -148,6 +148,17 @@ __device__ __forceinline__ void sched_pattern(std::integer_sequence<int, I...>) 
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0), __builtin_amdgcn_sched_group_barrier(0x020, I < NLOADS ? 1 : 0, 0)),
      ...);
 }
+// the same with the reads up front: one behind each of the first NREADS MFMAs, then the rest of the MFMAs.  For the cooperative
+// forms whose waves hold ONE tile (12, 8 and 6 CUs per board): dealt out "evenly", a channel group's only read came behind all four
+// of its MFMAs and was waited for at once -- the whole LDS latency, once per group (round 6: requests of up to 32 tasks 83 -> 79 us,
+// two tasks 60 -> 56, 33 tasks 90 -> 87; forms whose waves hold three or four tiles measured the same either way and keep the even deal)
+template <int NMFMA, int NREADS, int NLOADS, int... I>
+__device__ __forceinline__ void sched_front(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0), __builtin_amdgcn_sched_group_barrier(0x100, 1, 0),
+      __builtin_amdgcn_sched_group_barrier(0x020, I < NLOADS ? 1 : 0, 0)),
+     ...);
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NREADS, 0);
+}
 template <int NB>
 struct Tiles {
     static_assert(NB >= 1 && NB <= 3, "tiles are laid out for 1-, 2- and 3-board workgroups");
@@ -163,6 +174,7 @@ struct Tiles {
     static constexpr int X0 = NB == 1 ? -1 : 0, X1 = NB == 2 ? 1 : -1;
     static constexpr int Y0a = NB == 3 ? 6 : NB == 2 ? 9 : 4, Y0b = NB == 3 ? 8 : NB == 2 ? 10 : 5, Y1 = NB == 2 ? 10 : NB == 1 ? 5 : -1;
     static constexpr bool WM_EDGES = NB == 3;           // the two position groups hold opposite edges
+    static constexpr bool FRONT = false;                // (conv_layer, sched_front)
     static constexpr bool DB2 = NB != 3;                // second chain: double-buffered fragments too (conv_layer) where registers allow
     static constexpr int RING = 4;                      // slots of the weight ring (groups fetched RING - 1 ahead)
 };
@@ -357,8 +369,9 @@ __device__ __forceinline__ void conv_layer(const char* actb, const float* __rest
             for (int rt = 0; rt < RT; ++rt) next_a(rt);
             mfmas(1, JN, TA0{}, TA1{}, nothing);
 #ifndef BK_PHASE_FENCES
-            // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs
-            sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
+            // spread the RT activation reads and the CTW weight loads evenly between the interior tiles' MFMAs (F::FRONT: up front)
+            if constexpr (F::FRONT && (F::A1 - F::A0) * CTW * JN >= RT) sched_front<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
+            else sched_pattern<(F::A1 - F::A0) * CTW * JN, RT, CTW>(std::make_integer_sequence<int, RT>{});
 #endif
             PHASE_FENCE;
             if constexpr (F::X0 >= 0) { if (!sx0) mfmas(0, JN, std::integral_constant<int, F::X0>{}, std::integral_constant<int, F::X0 + 1>{}, nothing); }
@@ -803,6 +816,7 @@ struct CoopTiles {
     }
     static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = CT * RH, THREADS = 64 * NW;
+    static constexpr bool FRONT = RT == 1;              // a wave that holds ONE tile: the channel group's only read right behind its first MFMA (sched_front)
     static constexpr int XCHG_FLOATS = 2 * 81 * 128;    // per task: two layer parities
 };
 constexpr int COOP_SPIN_LIMIT = 1 << 15;
@@ -1004,7 +1018,7 @@ struct Coop3Tiles {
     static constexpr int CT = 8 / SC;                   // cout tiles per workgroup
     static constexpr int NW = WM * CT, THREADS = 64 * NW;
     static constexpr int A0 = 1, A1 = 6, X0 = 0, X1 = -1, Y0a = 6, Y0b = 8, Y1 = -1;   // as Tiles<3>
-    static constexpr bool WM_EDGES = true, DB2 = true;
+    static constexpr bool WM_EDGES = true, DB2 = true, FRONT = false;
     static constexpr int RING = 4;
     static constexpr int XCHG_FLOATS = 2 * 243 * 128;   // per group: two layer parities
 };
@@ -1021,7 +1035,7 @@ struct Coop3Tiles8 {
     static constexpr int NW = 4, THREADS = 64 * NW;
     static constexpr int A0 = H == 0 ? 1 : 0, A1 = H == 0 ? 4 : 2, X0 = H == 0 ? 0 : -1, X1 = -1;
     static constexpr int Y0a = H == 0 ? -1 : 2, Y0b = H == 0 ? -1 : 4, Y1 = -1;
-    static constexpr bool WM_EDGES = true, DB2 = true;
+    static constexpr bool WM_EDGES = true, DB2 = true, FRONT = false;
     static constexpr int RING = 4;
     static constexpr int XCHG_FLOATS = 2 * 243 * 128;
 };

@@ -43,6 +43,9 @@ for k, v in agg.items():
     print(f"  {k:40s} {v:9.0f} cycles  {100 * v / tot:5.1f} %   ({v / 7:7.0f} per layer)")
 per_layer_meet = [np.median(w[:, 4 + 4 * L] - w[:, 3 + 4 * L]) for L in range(7)]
 print("  meet per layer:", [int(v) for v in per_layer_meet])
+print("  conv per layer:", [int(np.median(w[:, 2 + 4 * L] - (w[:, 1] if L == 0 else w[:, 5 + 4 * (L - 1)]))) for L in range(7)])
+print("  store per layer:", [int(np.median(w[:, 3 + 4 * L] - w[:, 2 + 4 * L])) for L in range(7)])
+print("  fetch per layer:", [int(np.median(w[:, 5 + 4 * L] - w[:, 4 + 4 * L])) for L in range(7)])
 pk = w[:, 31]
 if (pk > 0).all():
     print("  staging in detail (cycles): stamp(0) -> loads issued = the rest |  zeroing LDS", int(np.median(pk & 0xffff)), "| waiting at the barrier (loads landing)",
