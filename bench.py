@@ -46,6 +46,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_LEAF = 266_838_272          # SURVEY 8d / BASELINE.md 3: valid taps, both nets
+FLOP_POLICY_EVAL = 133_413_888       # ... of which the PolicyNet (66,706,944 MAC) ...
+FLOP_VALUE_EVAL = 133_424_384        # ... and the ValueNet (66,712,192 MAC)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md chip table (dense, fp32 in / fp32 acc)
 PEAK_F16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md chip table (dense f16/bf16 MFMA)
 PEAK_HBM_GBPS = 8000.0               # MI355X_MICROARCH.md chip table (HBM3E)
@@ -973,14 +975,35 @@ def main():
             local, total = selfplay.self_play(ev, n_games=n_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads_for(mine),
                                               reduce_device=red)
             per_rank_s = gather(local["seconds"])
-            reduce_ms = gather(local["allreduce_s"] * 1e3)
+            reduce_ms = gather(local["allreduce_s"] * 1e3)          # the collective alone (every rank waited at a barrier first) ...
+            wait_ms = gather(local["allreduce_wait_s"] * 1e3)       # ... and that wait: how long before the slowest rank this one was done
             secs = max(per_rank_s)
-            return {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs,
+            # the leg on the roofline ("report games/min, leaf-evals/s/GPU"): network evaluations the generation asked
+            # for x their algorithmic FLOP, over the leg's seconds -- whole job against n_gpus x the fp32-MFMA peak, and rank by rank
+            i_val, i_pol = selfplay.STATS_FIELDS.index("value_evals"), selfplay.STATS_FIELDS.index("policy_evals")
+            rank_val, rank_pol = gather(float(local["local_stats"][i_val])), gather(float(local["local_stats"][i_pol]))
+            req, sent = gather(float(local["rows_requested"])), gather(float(local["rows_sent"]))
+            flop = total["policy_evals"] * FLOP_POLICY_EVAL + total["value_evals"] * FLOP_VALUE_EVAL
+            peak = PEAK_F16_MFMA_TFLOPS if prec == "f16x2" else PEAK_FP32_MFMA_TFLOPS
+            rank_tf = [(p * FLOP_POLICY_EVAL + v * FLOP_VALUE_EVAL) / t / 1e12 if t > 0 else 0.0 for p, v, t in zip(rank_pol, rank_val, per_rank_s)]
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "policy_evals": int(total["policy_evals"]), "value_evals": int(total["value_evals"]),
+                    "algorithmic_flop": float(flop), "flop_per_policy_eval": FLOP_POLICY_EVAL, "flop_per_value_eval": FLOP_VALUE_EVAL,
+                    "achieved_tflops": flop / secs / 1e12, "peak": peak * world, "frac": flop / secs / 1e12 / (peak * world),
+                    "per_rank_achieved_tflops": rank_tf, "per_rank_frac": [t / peak for t in rank_tf],
+                    # equal rows of one batch travel once (in-batch de-duplication) while every asker counts its evaluation: what the
+                    # GPU executed is the smaller number
+                    "rows_sent_over_rows_requested": sum(sent) / sum(req) if sum(req) > 0 else 1.0,
+                    "frac_of_rows_sent": flop / secs / 1e12 / (peak * world) * (sum(sent) / sum(req) if sum(req) > 0 else 1.0),
+                    "what": "evaluations the searches asked for (reduced vector: policy_evals, value_evals) x algorithmic FLOP (valid taps) "
+                            "/ the leg's seconds (max over ranks), end to end: host, launches and copies included"}
+            return {"games": total["games"], "games_per_min": total["games"] / secs * 60, "seconds": secs, "roofline": roof,
+                    "leaf_evals_per_s_per_gpu": (total["policy_evals"] + total["value_evals"]) / 2 / secs / world,
                     "per_rank_seconds": per_rank_s, "per_rank_seconds_min": min(per_rank_s), "per_rank_seconds_max": secs,
                     "games_per_rank": mine, "host_threads": threads_for(mine), "plies": total["plies"], "value_evals": total["value_evals"],
                     "value_evals_per_s": total["value_evals"] / secs,
                     "children_evaluated_per_expansion": selfplay.default_eager_top(prec, mine),
                     "black_wins": total["black_wins"], "stats_allreduce_ms": max(reduce_ms), "stats_allreduce_ms_per_rank": reduce_ms,
+                    "allreduce_wait_ms_per_rank": wait_ms, "value_sums_exact": total["value_sums_exact"],
                     "first_move_hist_sum": int(sum(total["first_move_hist"])),
                     # north_star: "all-reduce visit/value statistics at the end of a generation"
                     "root_visit_hist_sum": int(sum(total["root_visit_hist"])), "root_visit_hist_top5": sorted(
@@ -1026,6 +1049,17 @@ def main():
     # host exactly as a 1-GPU run does.
     ranks_seen = dist.get_world_size() if dist is not None else 1
     dist_backend = backend if dist is not None else None
+    # which fabric and which cards the line was measured on: RCCL's version and every rank's device ordinal + PCI address
+    rccl_version = None
+    if dist is not None and backend == "nccl":
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # noqa: BLE001  (a field of the line, not a reason to lose it)
+            rccl_version = f"unknown ({type(exc).__name__})"
+    props = torch.cuda.get_device_properties(local_rank)
+    pci_code = float((getattr(props, "pci_domain_id", 0) << 16) | (getattr(props, "pci_bus_id", 0) << 8) | getattr(props, "pci_device_id", 0))
+    rank_devices = [{"rank": r, "device": int(d), "pci": f"{int(c) >> 16:04x}:{(int(c) >> 8) & 0xff:02x}:{int(c) & 0xff:02x}.0"}
+                    for r, (d, c) in enumerate(zip(gather(float(local_rank)), gather(pci_code)))]
     rank0_cpus = format_cpulist(os.sched_getaffinity(0)) if "BK_BENCH_CPUS" in os.environ else None
     others = None
     if dist is not None:      # (the tensor collective the line's other fields use, not all_gather_object: nothing new for RCCL's first N > 1 run)
@@ -1070,6 +1104,9 @@ def main():
             "small_batch_latency": small,
             "collective_ranks_seen": ranks_seen,
             "collective_backend": dist_backend,
+            "rccl_version": rccl_version,
+            "rank_devices": rank_devices,
+            "device_name": props.name,
             "per_rank_leaf_evals_per_s": per_rank,
             "launched_by": ("torch.distributed.run" if os.environ.get("BK_BENCH_PINNED_BY") == "rank" or
                             ("TORCHELASTIC_RUN_ID" in os.environ and "BK_BENCH_CPUS" not in os.environ) else

@@ -25,6 +25,9 @@ COMM_SYMBOLS = {
     "bk_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, ctypes.POINTER(_VP)]),
     "bk_comm_allreduce_sum_f64": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
     "bk_comm_broadcast_f32": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int]),
+    "bk_comm_barrier": (ctypes.c_int, [_VP]),
+    "bk_comm_rccl_version": (ctypes.c_int, []),
+    "bk_comm_device_pci": (ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int]),
     "bk_comm_rank": (ctypes.c_int, [_VP]),
     "bk_comm_world": (ctypes.c_int, [_VP]),
     "bk_comm_destroy": (ctypes.c_int, [_VP]),
@@ -52,6 +55,7 @@ def commlib():
 
 class NativeComm:
     def __init__(self, rank, world, device_id, unique_id):
+        self._h = None                       # (first: __del__ runs close() also when anything below raises -- a missing libbkcomm.so)
         self._lib = commlib()
         if len(unique_id) != ID_BYTES:
             raise ValueError("unique_id must be 128 bytes")
@@ -135,6 +139,20 @@ class NativeComm:
             raise RuntimeError("bk_comm_allreduce_sum_f64: " + self._lib.bk_comm_last_error().decode())
         return a
 
+    def barrier(self):
+        """All ranks have arrived (a one-word all-reduce): in front of a timed collective, so that its time is not the wait."""
+        if self._lib.bk_comm_barrier(self._h):
+            raise RuntimeError("bk_comm_barrier: " + self._lib.bk_comm_last_error().decode())
+
+    def rccl_version(self):
+        return int(self._lib.bk_comm_rccl_version())
+
+    def device_pci(self):
+        buf = ctypes.create_string_buffer(32)
+        if self._lib.bk_comm_device_pci(self._h, buf, 32):
+            raise RuntimeError("bk_comm_device_pci: " + self._lib.bk_comm_last_error().decode())
+        return buf.value.decode()
+
     def broadcast_f32(self, vec, root=0):
         """rank `root`'s float32 vector to every rank (in place on a contiguous array; returns it)."""
         a = np.ascontiguousarray(vec, np.float32)
@@ -143,7 +161,7 @@ class NativeComm:
         return a
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             self._lib.bk_comm_destroy(self._h)
             self._h = None
 

@@ -43,7 +43,7 @@ int fail(const std::string& m) {
 
 extern "C" {
 
-int bk_comm_abi_version(void) { return 1; }
+int bk_comm_abi_version(void) { return 2; }
 
 const char* bk_comm_last_error(void) { return g_err.c_str(); }
 
@@ -107,6 +107,26 @@ int bk_comm_broadcast_f32(bk_comm* c, float* buf, int64_t n, int root) {
     TRY_NCCL(ncclBroadcast(c->d_bc, c->d_bc, (size_t)n, ncclFloat, root, c->comm, c->stream));
     if (c->rank != root) TRY_HIP(hipMemcpyAsync(buf, c->d_bc, bytes, hipMemcpyDeviceToHost, c->stream));
     TRY_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bk_comm_barrier(bk_comm* c) {
+    if (!c) return fail("comm is NULL");
+    TRY_HIP(hipSetDevice(c->device));
+    TRY_HIP(hipMemsetAsync(c->d_buf, 0, sizeof(double), c->stream));
+    TRY_NCCL(ncclAllReduce(c->d_buf, c->d_buf, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    TRY_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bk_comm_rccl_version(void) {
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : -1;
+}
+
+int bk_comm_device_pci(const bk_comm* c, char* out, int cap) {
+    if (!c || !out || cap < 16) return fail("comm or out is NULL, or cap < 16");
+    TRY_HIP(hipDeviceGetPCIBusId(out, cap, c->device));
     return 0;
 }
 

@@ -1255,6 +1255,20 @@ int bk_engine_set_option(bk_engine* e, const char* name, int value) {
     if (!e || !name) return BK_ERR_ARG;
     int* f = option_field(e, name);
     if (!f) return fail(e, BK_ERR_ARG, std::string("unknown engine option '") + name + "'");
+    // the switches are plain ints that submissions read: like every other call on an engine handle (single consumer)
+    // this one belongs to the thread that submits, between two submissions; values a switch does not know are refused, not ignored
+    const std::string n = name;
+    auto one_of = [&](std::initializer_list<int> ok) { return std::find(ok.begin(), ok.end(), value) != ok.end(); };
+    bool ok = true;
+    if (n == "force_nb") ok = value >= 0 && value <= 3;
+    else if (n == "coop") ok = one_of({-1, 0, 2, 3, 4, 6, 8, 12});
+    else if (n == "coop3") ok = one_of({-1, 0, 2, 4, 8});
+    else if (n == "copy_threads") ok = value >= 0 && value <= 64;
+    else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap, the test hooks
+    if (!ok) return fail(e, BK_ERR_ARG, std::string("engine option '") + name + "': value " + std::to_string(value) + " out of range");
+    for (const auto& sl : e->slots)
+        if (sl.busy && (n == "coop" || n == "coop3" || n == "force_nb" || n == "no_split"))
+            return fail(e, BK_ERR_ARG, std::string("engine option '") + name + "' changes the launch planner: wait for the tickets in flight first");
     *f = value;
     return BK_OK;
 }

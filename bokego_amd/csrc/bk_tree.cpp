@@ -510,7 +510,7 @@ struct Game {
     }
 
     void add_noise(int id) {  // mcts.py:366-369 with a per-game generator
-        if (prm.noise_weight <= 0.f) return;
+        if (prm.noise_weight <= 0.f || !nodes[id].has_prior) return;   // (a restored game whose root has no priors yet: nothing to mix into)
         double g[81], sum = 0;
         for (auto& x : g) { x = rng.gamma(0.1); sum += x; }
         double* p = &priors[nodes[id].prior_off];
@@ -787,6 +787,7 @@ struct bk_pool {
     std::vector<int> active;      // games included in the last collect, in batch order
     std::vector<int> pol_off, val_off;
     int threads = 1;
+    bool lanes = true;                 // bk_pool_set_lanes: games stay with "their" worker thread (run_lanes)
     std::vector<int> lane_items[64];   // scratch of run_lanes
     // in-batch de-duplication (bk_pool_set_dedup): rows of one batch that are the same position record -- games that are still in
     // the same opening -- travel once; row_of[a] = for the a-th active game the batch row of each of its request rows (policy
@@ -1051,10 +1052,11 @@ std::atomic<Team*> Team::instance_{nullptr};
 // game_of(i).  Against handing items out one by one from a single counter: advance phase -10...-18 % on the EPYC host
 // (tools/host_tree_bench.py); deliveries, single-threaded before (they touched every tree from the calling thread, i.e. pulled
 // it out of its lane's caches), run in the lanes as well: f16x2 self-play 0.50 -> 0.42-0.44 s per 512-game generation.
-// BK_NO_LANES=1: the single counter (and serial deliveries).
+// bk_pool_set_lanes(p, 0): the single counter (and serial deliveries) -- a switch of the pool, not of the environment: no request
+// path of these libraries reads the environment.
 template <typename GameOf, typename Fn>
 void run_lanes(bk_pool* p, int n, GameOf game_of, Fn fn) {
-    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
+    const bool lanes = p->lanes;
     const int T = std::min(std::min(p->threads, (int)p->games.size()), 64);
     if (!lanes || T <= 1 || n <= 1) {
         Team::get().run(T, n, fn);
@@ -1273,6 +1275,7 @@ int collect_dedup(bk_pool* p, bk_pos* out, int cap, int* n_policy) {
 }  // namespace
 
 void bk_pool_set_dedup(bk_pool* p, int on) { p->dedup = on != 0; }
+void bk_pool_set_lanes(bk_pool* p, int on) { p->lanes = on != 0; }
 void bk_pool_dedup_rows(const bk_pool* p, uint64_t* requested, uint64_t* sent) {
     *requested = p->rows_requested;
     *sent = p->rows_sent;
@@ -1382,8 +1385,8 @@ void bk_pool_deliver(bk_pool* p, const float* probs, const float* values) {
         gm.req_policy.clear();
         gm.req_value.clear();
     };
-    // in the games' lanes (with a single hand-out counter a parallel delivery cost more than it saved; BK_NO_LANES keeps it serial)
-    static const bool lanes = getenv("BK_NO_LANES") == nullptr;
+    // in the games' lanes (with a single hand-out counter a parallel delivery cost more than it saved; bk_pool_set_lanes(p, 0) keeps it serial)
+    const bool lanes = p->lanes;
     if (lanes && npol + nval >= 64) run_lanes(p, A, [&](int a) { return p->active[a]; }, deliver_game);
     else for (int a = 0; a < A; ++a) deliver_game(a);
     p->active.clear();
@@ -1743,9 +1746,27 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
     auto all_ok = [&](const std::vector<int>& v) { return std::all_of(v.begin(), v.end(), node_ok); };
     if (gm.poses.size() != gm.nodes.size() || (gm.prm.simulate ? gm.Qs.size() != gm.nodes.size() : !gm.Qs.empty())) return false;
     if (gm.state < S_INIT || gm.state > S_IDLE || gm.remaining < 0) return false;
+    // the search parameters and the request limit travel with the game: what the step loop divides by, indexes with or sizes
+    // requests from must be in range (a patched row_cap of -5 or a wild branch_num was taken as it came)
+    {
+        const bk_search_params& q = gm.prm;
+        auto in = [](long v, long lo, long hi) { return v >= lo && v <= hi; };
+        auto fin = [](double v, double lo, double hi) { return v >= lo && v <= hi; };          // (false for a NaN)
+        if (!in(q.rollouts, 0, 1 << 24) || !in(q.expand_thresh, 0, 1 << 30) || !fin(q.c_puct, 0.0, 1e6) || !fin(q.noise_weight, 0.0, 1.0) ||
+            !in(q.sample_plies, 0, 1 << 20) || !in(q.max_turns, 0, 100000) || !in(q.eager, 0, 1) || !fin(q.komi, -1000.0, 1000.0) ||
+            !in(q.record_visits, 0, 1) || !in(q.prune, 0, 1) || !in(q.speculate, 0, 1 << 30) || !in(q.speculate_rows, 0, 1 << 30) ||
+            !in(q.request_tasks, 0, 1 << 30) || !in(q.eager_top, 0, 81) || !in(q.branch_num, 0, 81) || !in(q.simulate, 0, 1) ||
+            !in(q.use_value, 0, 1) || !fin(q.value_weight, 0.0, 1.0))
+            return false;
+        for (int v : q.request_steps)
+            if (!in(v, 0, 1 << 30)) return false;
+        if (!q.use_value && !q.simulate) return false;                       // (bk_search_params: no value net needs simulate)
+        if (gm.row_cap < 1) return false;
+    }
     if (n == 0 ? gm.root != -1 : !node_ok(gm.root)) return false;
     if (gm.pending_expand != -1 && !node_ok(gm.pending_expand)) return false;
     if (gm.po != -1 || gm.po_mark != -1 || !gm.po_priors.empty()) return false;       // never in the middle of a playout
+    if (!gm.req_policy.empty() || !gm.req_value.empty()) return false;                // ... nor with a request out (bk_pool_snapshot refuses both)
     if (!all_ok(gm.kid_ids) || !all_ok(gm.path) || !all_ok(gm.req_policy) || !all_ok(gm.req_value) || !all_ok(gm.spec_queue) || !all_ok(gm.spill)) return false;
     for (const auto* m : {&gm.spec_kids, &gm.variations})
         for (const auto& kv : *m)
@@ -1762,15 +1783,34 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
     for (const TNode& nd : gm.nodes) {
         if (nd.n_kids < 0 || nd.kids_off < 0 || (size_t)nd.kids_off + (size_t)nd.n_kids > gm.kid_ids.size()) return false;
         if (nd.has_prior && (nd.prior_off < 0 || (size_t)nd.prior_off + 81 > gm.priors.size())) return false;
-        // a node with children is selected through its priors and its children's moves: both must be there
-        // (an expansion whose policy row is still in the request list is the one exception)
-        if (nd.n_kids > 0 && !nd.has_prior &&
-            std::find(gm.req_policy.begin(), gm.req_policy.end(), (int)(&nd - gm.nodes.data())) == gm.req_policy.end()) return false;
+        // a node with children is selected through its priors and its children's moves: both must be there (no request is out
+        // when a snapshot is taken, so no expansion is waiting for its policy row)
+        if (nd.n_kids > 0 && !nd.has_prior) return false;
         for (int k = 0; k < nd.n_kids; ++k) {
             const int mv = gm.nodes[gm.kid_ids[nd.kids_off + k]].mv;
             if (mv < 0 || mv >= 81) return false;
         }
     }
+    // state and path belong together: the states that come back to the last rollout (its leaf's value is out, its playout runs) walk
+    // `path` from the root down -- it must be there, start at the root and follow the tree's own edges; every other state starts
+    // its next rollout with path.clear() and the writer leaves it out (a snapshot patched to S_WAIT_LEAF with an empty
+    // path was accepted, and the next collect read path.back())
+    if (gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT) {
+        if (gm.path.empty() || gm.path[0] != gm.root) return false;
+        if (gm.state == S_PLAYOUT && !gm.prm.simulate) return false;
+        for (size_t i = 0; i + 1 < gm.path.size(); ++i) {
+            const TNode& nd = gm.nodes[(size_t)gm.path[i]];
+            const int* k0 = gm.kid_ids.data() + nd.kids_off;
+            if (std::find(k0, k0 + nd.n_kids, gm.path[i + 1]) == k0 + nd.n_kids) return false;
+        }
+    } else if (!gm.path.empty()) {
+        return false;
+    }
+    // states that index nodes[root] need a root (and what they read of it); a pending expansion is looked at in the waiting states only
+    if (n == 0 && gm.state != S_INIT) return false;
+    if (gm.state == S_ROOT_READY && !gm.nodes[(size_t)gm.root].has_prior) return false;       // add_noise mixes into the root's priors
+    if (gm.state == S_CHOOSE && gm.nodes[(size_t)gm.root].n_kids == 0) return false;          // pick_move returns one of the root's children
+    if (gm.pending_expand != -1 && gm.state != S_WAIT_ROOT && gm.state != S_WAIT_LEAF && gm.state != S_PLAYOUT) return false;
     gm.table_rebuild(gm.nodes.size());
     dst = std::move(gm);
     return true;
@@ -1829,25 +1869,40 @@ int bk_pools_run(bk_pool* const* pools, int n_pools, const bk_evaluator* ev, int
     }
     bk_run_info info{};
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = 0;
+    int rc = 0, out_now = 0;
+    // wait for lane j's request and hand its rows to the pool.  A ticket that has been waited for is spent whatever the outcome: it
+    // is cleared BEFORE the result is looked at, so that the clean-up below does not wait for it a second time (the engine would
+    // answer "unknown ticket" and that message would replace the real cause in bk_last_error: ADVICE r5)
+    auto finish = [&](int j) -> int {
+        Lane& l = lanes[(size_t)j];
+        const auto w0 = std::chrono::steady_clock::now();
+        const int wrc = ev->wait(ev->ctx, l.ticket);
+        info.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        l.ticket = 0;
+        --out_now;
+        if (wrc) return wrc < 0 ? wrc : -wrc;
+        bk_normalise_rows(l.probs.data(), l.npol);                  // Categorical(probs) re-normalises (nnet.py:274)
+        bk_pool_deliver(pools[j], l.probs.data(), l.values.data());
+        return 0;
+    };
     for (bool busy = true; busy && !rc;) {
         busy = false;
         for (int i = 0; i < n_pools && !rc; ++i) {
             Lane& l = lanes[(size_t)i];
-            if (l.ticket) {
-                const auto w0 = std::chrono::steady_clock::now();
-                const int wrc = ev->wait(ev->ctx, l.ticket);
-                info.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                if (wrc) { rc = wrc < 0 ? wrc : -wrc; break; }
-                bk_normalise_rows(l.probs.data(), l.npol);          // Categorical(probs) re-normalises (nnet.py:274)
-                bk_pool_deliver(pools[i], l.probs.data(), l.values.data());
-                l.ticket = 0;
-            }
+            if (l.ticket && (rc = finish(i))) break;
             if (l.live) {
                 l.n = bk_pool_collect_pos(pools[i], l.recs.data(), cap, &l.npol);
                 if (l.n == 0) { l.live = false; continue; }
+                // never more than BK_POOLS_MAX_INFLIGHT requests out (the engine's evaluator has BK_MAX_INFLIGHT = 4 tickets): with
+                // more pools than that the oldest request -- the next lane in turn that has one -- is taken in first
+                for (int d = 1; out_now >= BK_POOLS_MAX_INFLIGHT && d < n_pools && !rc; ++d) {
+                    const int j = (i + d) % n_pools;
+                    if (lanes[(size_t)j].ticket) rc = finish(j);
+                }
+                if (rc) break;
                 l.ticket = ev->submit(ev->ctx, l.recs.data(), l.n, l.npol, l.probs.data(), l.values.data());
                 if (l.ticket <= 0) { rc = l.ticket < 0 ? (int)l.ticket : -1; l.ticket = 0; break; }
+                ++out_now;
                 info.steps += 1;
                 info.rows += (uint64_t)l.n;
                 info.policy_rows += (uint64_t)l.npol;

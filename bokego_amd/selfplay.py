@@ -76,6 +76,7 @@ TREE_SYMBOLS = {
     "bk_pool_deliver": (None, [_VP, _VP, _VP]),
     "bk_pool_phase_seconds": (None, [_VP, _VP]),
     "bk_pool_set_dedup": (None, [_VP, ctypes.c_int]),
+    "bk_pool_set_lanes": (None, [_VP, ctypes.c_int]),
     "bk_pool_dedup_rows": (None, [_VP, _VP, _VP]),
     "bk_team_selftest": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "bk_team_selftest_concurrent": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
@@ -211,6 +212,10 @@ class GamePool:
     def set_dedup(self, on=True):
         """In-batch de-duplication of collect_positions() (bk_pool_set_dedup): equal records travel once."""
         self._lib.bk_pool_set_dedup(self._h, int(bool(on)))
+
+    def set_lanes(self, on=True):
+        """Games keep to "their" worker thread (bk_pool_set_lanes; on by default).  Speed only: same games either way."""
+        self._lib.bk_pool_set_lanes(self._h, int(bool(on)))
 
     def dedup_rows(self):
         """(rows the games asked for, rows that travelled) since the pool was created, with de-duplication on."""
@@ -442,8 +447,11 @@ def run_pools(pools, evaluator, progress=None):
 #       chosen (2 winrate - 1 from the side to move, mcts.py:159-170), its magnitude, and the number of plies
 #   first_move_hist[81]      games by their first move
 #   root_visit_hist[81]      sum over every ply of every game of the root's children's visit counts, by move (mcts.py:122-128)
-# Every entry is an integer or a multiple of 2^-32 far below 2^53 in magnitude: the sums are exact in float64, so the reduced
-# vector does not depend on the order of addition (world size, ring order).  173 doubles = 1,384 bytes.
+# Every entry is an integer or a multiple of 2^-32: a float64 sum of such numbers is exact -- and so independent of the order of
+# addition (world size, ring order) -- as long as its magnitude stays below 2^53 * 2^-32 = 2^21.  The counters are far from that;
+# the two value sums grow by at most 1 per ply, so the statement holds for generations of fewer than 2^21 = 2,097,152 plies (about
+# 26,000 games; configs[3] has 512): named_stats() says so in "value_sums_exact", and EXACT_PLIES is the bound.  173 doubles = 1,384 bytes.
+EXACT_PLIES = 1 << 21
 STATS_FIELDS = ["games", "black_wins", "white_wins", "plies", "sum_score", "value_evals", "policy_evals", "requests",
                 "sum_root_value", "sum_abs_root_value", "n_root_values"]
 STATS_HISTS = ["first_move_hist", "root_visit_hist"]
@@ -481,30 +489,48 @@ def named_stats(total):
     for j, h in enumerate(STATS_HISTS):
         at = len(STATS_FIELDS) + 81 * j
         named[h] = [int(round(x)) for x in total[at:at + 81]]
+    named["value_sums_exact"] = bool(named["n_root_values"] < EXACT_PLIES)    # (beyond: still right to ~1e-16 relative, but order-dependent)
     named["mean_root_value"] = named["sum_root_value"] / named["n_root_values"] if named["n_root_values"] else 0.0
     named["mean_abs_root_value"] = named["sum_abs_root_value"] / named["n_root_values"] if named["n_root_values"] else 0.0
     return named
 
 
-def all_reduce_stats(stats, device=None, native_comm=None):
+def all_reduce_stats(stats, device=None, native_comm=None, timing=None):
     """The generation's single collective: sum the statistics vector over ranks (no process group: no-op).
-    native_comm: a bokego_amd.comm.NativeComm -- the same all-reduce through libbkcomm.so instead of torch."""
+    native_comm: a bokego_amd.comm.NativeComm -- the same all-reduce through libbkcomm.so instead of torch.
+    Returns (the sums, seconds of the COLLECTIVE).  The ranks finish their games at different times, so a clock started at the call
+    would mostly measure the wait for the slowest rank (6 ranks on one card: 0.75 ms on the last rank to arrive, 485 ms on the
+    first): every rank first waits at a barrier -- timing["wait_s"], the skew -- and the all-reduce is timed alone behind it."""
     if native_comm is not None:
         t0 = time.perf_counter()
+        native_comm.barrier()
+        t1 = time.perf_counter()
         out = native_comm.allreduce_sum(stats)
-        return out, time.perf_counter() - t0
+        t2 = time.perf_counter()
+        if timing is not None:
+            timing["wait_s"] = t1 - t0
+        return out, t2 - t1
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
+        if timing is not None:
+            timing["wait_s"] = 0.0
         return stats, 0.0
     t = torch.from_numpy(stats.copy())
     if device is not None:
         t = t.to(device)
     t0 = time.perf_counter()
+    dist.barrier()
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if t.is_cuda:
         torch.cuda.synchronize()
-    return t.cpu().numpy(), time.perf_counter() - t0
+    t2 = time.perf_counter()
+    if timing is not None:
+        timing["wait_s"] = t1 - t0
+    return t.cpu().numpy(), t2 - t1
 
 
 def broadcast_weights(policy_sd, value_sd, src=0, device=None, native_comm=None):
@@ -677,12 +703,13 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
                 visits[g] = [pool.visits(i, ply) for ply in range(len(games[g]["moves"]))]
     local = pool_stats(pools) if pools else np.zeros(STATS_LEN)
     rows_req, rows_sent = (sum(x) for x in zip(*[p.dedup_rows() for p in pools])) if pools else (0, 0)
-    total, t_reduce = all_reduce_stats(local, reduce_device, native_comm)
+    timing = {}
+    total, t_reduce = all_reduce_stats(local, reduce_device, native_comm, timing)
     for p in pools:
         p.close()
     named = named_stats(total)
     return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local, "native_loop": bool(native_loop),
-             "n_pools": n_pools, "speculate": int(speculate), "task_caps": [int(c or 0) for c in caps], "allreduce_s": t_reduce, "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
+             "n_pools": n_pools, "speculate": int(speculate), "task_caps": [int(c or 0) for c in caps], "allreduce_s": t_reduce, "allreduce_wait_s": timing.get("wait_s", 0.0), "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
 
 
 # ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------

@@ -144,7 +144,9 @@ int main(int argc, char **argv) {
             for (int k = 0; k < 81; ++k) st[NSCAL + 81 + k] += (double)gs.root_visits[k];
             for (int k = 0; k < nm; ++k) check = (check ^ (unsigned short)mv[k]) * 1099511628211ull;
         }
-    double reduce_ms = 0;
+    double reduce_ms = 0, reduce_wait_ms = 0;
+    int rccl = 0;
+    char pci[32] = "";
     if (world > 1) {
         const char *idf = getenv("BK_COMM_ID_FILE");
         uint8_t id[BK_COMM_ID_BYTES];
@@ -174,9 +176,16 @@ int main(int argc, char **argv) {
         bk_comm *c = NULL;
         if (bk_comm_init(rank, world, id, device, &c)) { fprintf(stderr, "bk_comm_init: %s\n", bk_comm_last_error()); return 1; }
         if (rank == 0) remove(idf);   /* every rank has joined: the next run must not find this id */
+        /* the ranks finish their games at different times: wait for the slowest one at a barrier first (wait_ms: the skew), then time
+         * the all-reduce alone (allreduce_ms: the collective) */
         const double t1 = now();
+        if (bk_comm_barrier(c)) { fprintf(stderr, "barrier: %s\n", bk_comm_last_error()); return 1; }
+        const double t2 = now();
         if (bk_comm_allreduce_sum_f64(c, st, NST)) { fprintf(stderr, "allreduce: %s\n", bk_comm_last_error()); return 1; }
-        reduce_ms = (now() - t1) * 1e3;
+        reduce_ms = (now() - t2) * 1e3;
+        reduce_wait_ms = (t2 - t1) * 1e3;
+        rccl = bk_comm_rccl_version();
+        if (bk_comm_device_pci(c, pci, (int)sizeof pci)) pci[0] = 0;
         bk_comm_destroy(c);
     }
     double host[3] = {0, 0, 0};       /* seconds the pools spent advancing games / writing request rows / taking deliveries */
@@ -189,10 +198,10 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 81; ++k) visit_sum += st[NSCAL + 81 + k];
     if (rank == 0)
         printf("{\"games\": %.0f, \"local_games\": %d, \"seconds\": %.4f, \"local_games_per_min\": %.0f, \"steps\": %ld, \"mean_batch\": %.0f, "
-               "\"plies\": %.0f, \"black_wins\": %.0f, \"value_evals\": %.0f, \"policy_evals\": %.0f, \"allreduce_ms\": %.3f, "
+               "\"plies\": %.0f, \"black_wins\": %.0f, \"value_evals\": %.0f, \"policy_evals\": %.0f, \"allreduce_ms\": %.3f, \"allreduce_wait_ms\": %.3f, \"rccl_version\": %d, \"rank0_pci\": \"%s\", "
                "\"sum_root_value\": %.9f, \"sum_abs_root_value\": %.9f, \"n_root_values\": %.0f, \"root_visit_hist_sum\": %.0f, \"wait_s\": %.3f, "
                "\"host_advance_s\": %.3f, \"host_emit_s\": %.3f, \"host_deliver_s\": %.3f, \"moves_checksum\": \"%016llx\"}\n",
-               st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms,
+               st[0], mine, secs, mine / secs * 60, steps, steps ? (double)positions / steps : 0.0, st[3], st[1], st[5], st[6], reduce_ms, reduce_wait_ms, rccl, pci,
                st[8], st[9], st[10], visit_sum, info.wait_seconds,
                host[0], host[1], host[2], check);
     for (int i = 0; i < npools; ++i) bk_pool_destroy(s[i].pool);

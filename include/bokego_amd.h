@@ -214,7 +214,10 @@ int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every 
  * only.  Results never depend on any of them (every launch form is bit-identical); they exist so that tests and probes can
  * force each form.  Names: "force_nb" (0 | 1..3 boards per workgroup), "no_split", "coop" (-1 by task count | 0 off | 2, 3,
  * 4, 6, 8, 12 CUs per board), "coop3" (-1 | 0 | 2 | 4 | 8), "no_direct", "no_head_part", "copy_threads", "encode_overlap".
- * Unknown name: BK_ERR_ARG.  Builds with -DBK_TEST_HOOKS (bk_has_test_hooks() == 1; never shipped as libbokego_amd.so) add
+ * Unknown name or a value the switch does not know (coop = 5, copy_threads < 0): BK_ERR_ARG, nothing changed.  Like every call
+ * on an engine handle it belongs to the one thread that submits (the handle is single-consumer); the planner's switches
+ * ("force_nb", "no_split", "coop", "coop3") are refused while tickets are in flight -- a request's redo after a failed cooperative
+ * launch must see the plan its submission saw.  Builds with -DBK_TEST_HOOKS (bk_has_test_hooks() == 1; never shipped as libbokego_amd.so) add
  * "coop_fault" and "fault_submit" (fault injection for tests/test_gpu_hooks.py).
  */
 int bk_engine_set_option(bk_engine *e, const char *name, int value);

@@ -40,6 +40,13 @@ int bk_comm_allreduce_sum_f64(bk_comm *c, double *buf, int n);
  * both nets -- to every rank, in place: one ncclBroadcast through a device buffer grown on demand.  The reference
  * shares weights between its worker processes with share_memory() (bin/selfplay.py:171-175). */
 int bk_comm_broadcast_f32(bk_comm *c, float *buf, int64_t n, int root);
+/* every rank waits here until all have arrived (a one-word all-reduce): called in front of the statistics' all-reduce so that its
+ * time can be told from the wait for the slowest rank (bench.py: stats_allreduce_ms = the collective, allreduce_wait_ms = the skew) */
+int bk_comm_barrier(bk_comm *c);
+/* what the first multi-GPU line should say about its fabric: RCCL's version (ncclGetVersion: e.g. 22205) and the PCI address of
+ * the GPU this communicator drives ("0000:05:00.0"; cap >= 16) */
+int bk_comm_rccl_version(void);
+int bk_comm_device_pci(const bk_comm *c, char *out, int cap);
 int bk_comm_rank(const bk_comm *c);
 int bk_comm_world(const bk_comm *c);
 int bk_comm_destroy(bk_comm *c);

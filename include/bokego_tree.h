@@ -132,6 +132,11 @@ void bk_pool_phase_seconds(const bk_pool *p, double *out3);
  * keeps one memo for all trees (mcts.py:41-44); here a game has its own, and this is the part of the shared one that costs
  * nothing to keep exact: the networks' outputs for equal records are the same bits.  Per-game counters do not change. */
 void bk_pool_set_dedup(bk_pool *p, int on);
+/* Worker-thread affinity of the games (on by default): game g is advanced and delivered to by the same worker step after step, so
+ * its tree stays in that core's caches; 0 = items handed out one by one from a single counter, deliveries on the calling thread
+ * (what the environment variable BK_NO_LANES selected until round 5: no request path reads the environment any more).  Which
+ * thread works on a game never changes what the game computes. */
+void bk_pool_set_lanes(bk_pool *p, int on);
 void bk_pool_dedup_rows(const bk_pool *p, uint64_t *requested, uint64_t *sent);
 /* stress of the worker threads the pools share (`jobs` short parallel regions on `threads` threads); 0 = every item ran once */
 int bk_team_selftest(int threads, int jobs);
@@ -240,6 +245,7 @@ int bk_pool_restore(bk_pool *p, int g, const void *buf, long len);
  * Returns 0, -1 for bad arguments, or the evaluator's error code (outstanding tickets are waited for first; the pools are
  * then in the middle of a step and cannot be driven on).
  */
+#define BK_POOLS_MAX_INFLIGHT 4 /* bk_pools_run keeps at most this many requests out at once (= the engine's BK_MAX_INFLIGHT) */
 typedef struct bk_evaluator {
     void *ctx;
     int64_t (*submit)(void *ctx, const bk_pos *recs, int B, int n_policy, float *probs, float *values);

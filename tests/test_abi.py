@@ -172,7 +172,7 @@ def test_comm_library_symbols_and_cpu_errors():
     assert set(fns) == set(comm.COMM_SYMBOLS)
     for f in fns:
         assert hasattr(lib, f)
-    assert lib.bk_comm_abi_version() == 1
+    assert lib.bk_comm_abi_version() == 2
     import torch
     if not torch.cuda.is_available():
         h = ctypes.c_void_p()
@@ -221,5 +221,7 @@ def test_the_request_path_does_not_read_the_environment():
     inside = [u for u in uses if code.index("int bk_engine_create(") <= u < code.index("int bk_engine_destroy(")]
     helpers = [u for u in uses if u < code.index("struct bk_engine {")]          # the helper's own definition + the roctx loader
     assert len(inside) >= 8 and len(inside) + len(helpers) == len(uses) and "env_str" in create
-    for f in ("bk_kernels.hip", "bk_kernels_f16.hip", "bk_encode.hip"):
-        assert "getenv" not in open(os.path.join(REPO, "bokego_amd", "csrc", f)).read(), f
+    # ... nor do the tree / board library's (BK_NO_LANES is now the pool switch bk_pool_set_lanes) or the collective's
+    for f in ("bk_kernels.hip", "bk_kernels_f16.hip", "bk_encode.hip", "bk_tree.cpp", "bk_go.cpp", "bk_comm.cpp"):
+        code = re.sub(r"//[^\n]*", "", open(os.path.join(REPO, "bokego_amd", "csrc", f)).read())
+        assert not re.search(r"\bgetenv\s*\(", code), f

@@ -60,3 +60,24 @@ def test_job_tag_sources(monkeypatch):
     monkeypatch.setenv("BK_COMM_JOB", "nonce-1")
     b = comm.NativeComm._job_tag(None)
     assert a != b and b == comm.NativeComm._job_tag("nonce-1") and len(a) == 16
+
+
+def test_a_communicator_whose_constructor_failed_has_a_quiet_destructor(capsys, monkeypatch):
+    """NativeComm.__del__ -> close() read self._h before __init__ had set it -- a missing libbkcomm.so (or no
+    GPU: bk_comm_init refuses) printed `AttributeError: 'NativeComm' object has no attribute '_h'` from the destructor."""
+    import gc
+    monkeypatch.setattr(comm, "_lib", None)
+    monkeypatch.setattr(comm, "COMM_LIB_PATH", "/nonexistent/libbkcomm.so")
+    with pytest.raises(RuntimeError, match="not found"):
+        comm.NativeComm(0, 1, 0, bytes(128))
+    gc.collect()
+    assert "AttributeError" not in capsys.readouterr().err
+    monkeypatch.undo()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="bk_comm_init"):       # the library is there, the GPU is not
+            comm.NativeComm(0, 1, 0, bytes(128))
+        gc.collect()
+        assert "AttributeError" not in capsys.readouterr().err
+    c = comm.NativeComm.__new__(comm.NativeComm)
+    c.close()                                                            # no handle: nothing to do, no error

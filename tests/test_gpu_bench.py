@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--sustain", "0.3",
-                          "--no-cpu-baseline", "--no-selfplay"], capture_output=True, text=True, timeout=600, cwd=REPO)
+                          "--no-cpu-baseline", "--selfplay-games", "64"], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py prints exactly one line"
@@ -54,6 +54,18 @@ def test_bench_line_contract():
     assert f16["roofline"]["peak"] == 2500.0 and f16["value"] > d["value"]
     sb = d["small_batch_latency"]
     assert sb["B62"]["cooperative_us"] < 0.6 * sb["B62"]["one_cu_per_board_us"] and sb["B62"]["fallbacks"] == 0
+    # the self-play leg on the roofline, recomputable from the line alone
+    assert d["device_name"] and d["rank_devices"][0]["rank"] == 0 and len(d["rank_devices"][0]["pci"]) >= 12
+    for leg in ("f32", "f16x2"):
+        g = d["selfplay"][leg]
+        ro = g["roofline"]
+        flop = ro["policy_evals"] * 133_413_888 + ro["value_evals"] * 133_424_384
+        assert ro["policy_evals"] > 0 and ro["value_evals"] == g["value_evals"] and abs(ro["algorithmic_flop"] - flop) < 1e-6 * flop
+        assert abs(ro["achieved_tflops"] - flop / g["seconds"] / 1e12) < 1e-6 * ro["achieved_tflops"]
+        assert ro["peak"] == (157.3 if leg == "f32" else 2500.0) and abs(ro["frac"] - ro["achieved_tflops"] / ro["peak"]) < 1e-9
+        assert 0.01 < ro["frac"] < 1.0 and len(ro["per_rank_frac"]) == 1 and 0.5 < ro["rows_sent_over_rows_requested"] <= 1.0
+        assert g["stats_allreduce_ms"] == 0 and g["allreduce_wait_ms_per_rank"] == [0.0] and g["value_sums_exact"] is True
+    assert d["selfplay"]["weak"]["same_as"] == "f32"
 
 
 def test_bench_starts_its_own_ranks():
@@ -93,6 +105,10 @@ def test_bench_starts_its_own_ranks():
     assert f["n_root_values"] == f["plies"] and f["root_visit_hist_sum"] > 380 * f["plies"] and 0 < f["mean_abs_root_value"] < 1
     assert len(f["per_rank_seconds"]) == 2 and f["per_rank_seconds_min"] <= f["per_rank_seconds_max"] == f["seconds"]
     assert f["games_per_rank"] == 16 and len(f["stats_allreduce_ms_per_rank"]) == 2 and f["native_loop"]
+    # the collective timed apart from the wait for the slowest rank; which fabric, which cards
+    assert len(f["allreduce_wait_ms_per_rank"]) == 2 and all(v >= 0 for v in f["allreduce_wait_ms_per_rank"]) and f["stats_allreduce_ms"] < 200
+    assert len(f["roofline"]["per_rank_frac"]) == 2 and f["roofline"]["peak"] == 2 * 157.3
+    assert [x["rank"] for x in d["rank_devices"]] == [0, 1] and (d["rccl_version"] is not None) == real
     w = sp["weak"]
     assert w["games"] == 64 and w["games_per_rank"] == 32 and w["first_move_hist_sum"] == 64 and len(w["per_rank_seconds"]) == 2
     assert 0 < sp["strong_scaling_efficiency_vs_own_weak_leg"] < 1.5 and 0 < sp["weak_scaling_per_rank_seconds_min_over_max"] <= 1

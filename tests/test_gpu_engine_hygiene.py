@@ -93,3 +93,31 @@ def test_stats_do_not_wait_for_the_device(weights):
             break
     assert best < 1.02, f"a 1 kHz stats() poller slows the pipelined loop by {100 * (best - 1):.1f} %"
     eng.close()
+
+
+def test_engine_options_refuse_what_they_do_not_know(weights):
+    """bk_engine_set_option took any integer (coop = 5 was silently ignored by the planner, copy_threads = -1
+    taken) and changed the planner's switches under tickets in flight.  Unknown values are refused and leave the switch as it
+    was; the planner's switches wait for the tickets."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x8 = make_batch(4096, seed_base=6_100, dtype=np.uint8)
+    eng = LeafEngine(weights[0], weights[1], max_batch=4096)
+    for name, bad in (("coop", 5), ("coop", 7), ("coop3", 3), ("force_nb", 4), ("force_nb", -1), ("copy_threads", -1), ("no_split", 2)):
+        before = eng.get_option(name)
+        with pytest.raises((ValueError, RuntimeError), match="out of range"):
+            eng.set_option(name, bad)
+        assert eng.get_option(name) == before
+    for name, good in (("coop", 8), ("coop", -1), ("coop3", 8), ("coop3", -1), ("force_nb", 2), ("force_nb", 0), ("copy_threads", 0), ("copy_threads", 6)):
+        eng.set_option(name, good)
+        assert eng.get_option(name) == good
+    ref = eng.eval(x8, probs=True, value=True)
+    t = eng.submit(x8, probs=True, value=True)
+    with pytest.raises((ValueError, RuntimeError), match="in flight"):
+        eng.set_option("coop", 0)
+    eng.set_option("no_direct", 1)            # (not a planner switch: allowed)
+    eng.set_option("no_direct", 0)
+    assert _same(eng.wait(t), ref)
+    eng.set_option("coop", 0)
+    eng.set_option("coop", -1)
+    eng.close()

@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 HOOKS = L.HOOKS_LIB_PATH
 
 
+@pytest.fixture(scope="module", autouse=True)
+def hooks_library():
+    """The fault-injection build is the tests' own: normally it travels with the tree (`make all` builds it beside the shipped
+    library); where it is missing it is built here (`make hooks`, ~30 s), and a build without its hooks fails the module."""
+    import subprocess
+    if not os.path.exists(HOOKS):
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(HOOKS), "csrc"), "hooks"])
+    assert L.load(HOOKS).bk_has_test_hooks() == 1, "libbokego_amd_hooks.so was built without -DBK_TEST_HOOKS"
+
+
 @pytest.fixture(scope="module")
 def weights():
     return load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))

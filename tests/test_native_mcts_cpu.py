@@ -515,6 +515,93 @@ def test_a_snapshot_carries_a_self_play_game_across_pools():
     assert b.moves(1) == [] and b.info(1)["done"] == 0
 
 
+def _snapshot_layout(blob):
+    """Byte offsets of the search parameters and of the eight state words (root, state, remaining, pending_expand, po, po_mark,
+    po_reward, row_cap) in a bk_pool_snapshot blob: header (magic, version, three sizes), the parameters, five length-prefixed
+    arrays (nodes, positions, Q, child ids, priors), then the words."""
+    import struct
+    magic, version, sz_node, sz_pos, sz_prm = struct.unpack_from("<5I", blob, 0)
+    off = 20 + sz_prm
+    for elem in (sz_node, sz_pos, 8, 4, 8):
+        (n,) = struct.unpack_from("<Q", blob, off)
+        off += 8 + n * elem
+    return 20, sz_prm, off
+
+
+def test_restore_checks_state_words_and_parameters_one_field_at_a_time():
+    """bk_pool_restore range-checked each field but not their consistency -- a snapshot whose state word was
+    patched to S_WAIT_LEAF / S_PLAYOUT (its path is then empty) was accepted and the next collect read path.back(); row_cap = -5 and
+    wild search parameters were taken as they came.  Every single-field patch of the state words and of the parameters is now
+    either refused (the game stays as it was) or gives a game that can be STEPPED -- collect / deliver until its next move --
+    not only looked at.  (`make check` runs this under AddressSanitizer + UBSan.)"""
+    import struct
+    f = FakeNets()
+    prm = selfplay.search_params(rollouts=24, expand_thresh=4, noise_weight=0.25, sample_plies=2, max_turns=10, prune=0, record_visits=1,
+                                 eager_top=4, speculate=3)
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    src = selfplay.GamePool([11], prm, cap=256, threads=1)
+    while src.info(0)["n_moves"] < 3:
+        feats, npol = src.collect()
+        src.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
+    good = src.snapshot(0)
+    prm_off, prm_len, ints_off = _snapshot_layout(good)
+    state0 = struct.unpack_from("<i", good, ints_off + 4)[0]
+    dst = selfplay.GamePool([1], prm, cap=256, threads=1)
+
+    def step_a_while(pool):
+        for _ in range(60):                               # far enough for every state to come round (24 rollouts per move)
+            feats, npol = pool.collect()
+            if len(feats) == 0:
+                return
+            pool.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
+
+    def attempt(blob):
+        dst.restore(0, good)
+        before = (dst.moves(0), dst.info(0), dst.root_children(0))
+        try:
+            dst.restore(0, bytes(blob))
+        except ValueError:
+            assert (dst.moves(0), dst.info(0), dst.root_children(0)) == before
+            return False
+        step_a_while(dst)
+        return True
+
+    refused = accepted = 0
+    # the state word: every state, and values beyond the enumeration
+    for st in list(range(-1, 12)):
+        b = bytearray(good)
+        struct.pack_into("<i", b, ints_off + 4, st)
+        ok = attempt(b)
+        refused += not ok
+        accepted += ok
+        if st == state0:
+            assert ok
+        if st in (5, 6) and st != state0:                # S_PLAYOUT, S_WAIT_LEAF: the writer left the path out
+            assert not ok, st
+        if st < 0 or st > 9:
+            assert not ok, st
+    # the other state words
+    for word in range(8):
+        for val in (-5, -1, 0, 1, 7, 10**6, 2**31 - 1, -2**31):
+            b = bytearray(good)
+            struct.pack_into("<i", b, ints_off + 4 * word, val)
+            ok = attempt(b)
+            refused += not ok
+            accepted += ok
+            if word == 7 and val < 1:                    # row_cap
+                assert not ok, val
+    # the parameters, 32-bit word by word (integers, floats and halves of doubles alike)
+    rng = np.random.default_rng(5)
+    for w in range(prm_len // 4):
+        for val in (-1, 0, 1, 81, 82, 10**9, -2**31, int(rng.integers(-2**31, 2**31))):
+            b = bytearray(good)
+            struct.pack_into("<i", b, prm_off + 4 * w, val)
+            ok = attempt(b)
+            refused += not ok
+            accepted += ok
+    assert refused > 100 and accepted > 50, (refused, accepted)
+
+
 def test_the_default_launchers_tree_copies_and_pickles_with_its_protocol_state():
     """NativeGTP = the GTP front-end on the native tree, what `python -m bokego_amd.gtp` runs: a deep copy and a pickle carry the
     protocol's own state too (move history, komi, last root: the reference's MCTS.__getstate__ copies the whole __dict__,
@@ -540,8 +627,8 @@ def test_the_default_launchers_tree_copies_and_pickles_with_its_protocol_state()
 def test_restore_refuses_or_survives_corrupted_snapshots():
     """bk_pool_restore checks every index the search and the rules code would follow (node ids, edge and prior offsets, stone
     colours, ko and move points): 4,000 random corruptions of a real mid-game snapshot -- byte flips, truncations, spliced
-    garbage -- are either refused (the game stays as it was) or restored into a state every read-only view can walk.  Memory
-    safety, not plausibility: `make check` runs this under AddressSanitizer + UBSan."""
+    garbage -- are either refused (the game stays as it was) or restored into a state every read-only view can walk and the step
+    loop can advance.  Memory safety, not plausibility: `make check` runs this under AddressSanitizer + UBSan."""
     f = FakeNets()
     prm = selfplay.search_params(rollouts=40, expand_thresh=5, noise_weight=0.25, sample_plies=3, max_turns=12, prune=0, record_visits=1,
                                  eager_top=4, speculate=3)
@@ -590,6 +677,11 @@ def test_restore_refuses_or_survives_corrupted_snapshots():
         lib.bk_pool_principal_variation(dst._h, 0, mv16.ctypes.data, 128)
         lib.bk_pool_root_children(dst._h, 0, mv16.ctypes.data, n32.ctypes.data, v64.ctypes.data)
         assert len(dst.snapshot(0)) > 0
+        for _ in range(30):                                # ... and STEPPED (an accepted state the next collect fell over)
+            feats, npol = dst.collect()
+            if len(feats) == 0:
+                break
+            dst.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
         dst.restore(0, good)
         before = (dst.moves(0), dst.info(0), dst.root_children(0))
     assert refused > 1500 and accepted > 200, (refused, accepted)

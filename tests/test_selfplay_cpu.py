@@ -1,5 +1,6 @@
 """Host logic of config 4 on CPU: the native tree pool equals the Python MCTS visit for visit, games do
 not depend on sharding, and the end-of-generation all-reduce works with world_size 2 (gloo)."""
+import ctypes
 import os
 import socket
 
@@ -536,6 +537,77 @@ def test_native_step_loop_plays_the_same_games():
     # planes-only evaluators are refused with a clear message (the C loop hands over position records)
     with pytest.raises(TypeError):
         selfplay.self_play(selfplay.CallableEvaluator(f.policy, f.value), native_loop=True, **kw)
+
+
+def test_native_step_loop_keeps_to_the_evaluators_tickets():
+    """bk_pools_run (a) accepted up to 16 pools while the engine's evaluator has BK_MAX_INFLIGHT = 4 tickets -- a
+    fifth pool failed at submit with a generic error -- and (b) after a failed wait() waited for the same ticket again in its
+    clean-up, so that the engine's "unknown ticket" replaced the real cause in bk_last_error.  Driven here with an evaluator that
+    keeps books: never more than four tickets out, every ticket waited for exactly once, also when a wait fails; and six pools
+    play the games two pools play."""
+    f = FakeNets()
+    lib = selfplay.treelib()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    prm = selfplay.search_params(rollouts=30, expand_thresh=5, noise_weight=0.25, sample_plies=2, max_turns=9, eager_top=4)
+
+    def run(n_pools, fail_wait_at=None):
+        inner = selfplay.RecordEvaluator(pol, val)
+        book = {"next": 0, "out": set(), "max_out": 0, "waits": [], "double": 0}
+
+        def submit(_ctx, recs, B, n_policy, probs, values):
+            r = np.ctypeslib.as_array((ctypes.c_uint8 * (B * 192)).from_address(recs)).reshape(B, 192)
+            pr, v = inner.finish(inner.submit(r, n_policy), normalise=lambda x: x)
+            if n_policy:
+                np.ctypeslib.as_array((ctypes.c_float * (n_policy * 81)).from_address(probs))[:] = np.asarray(pr, np.float32).reshape(-1)
+            np.ctypeslib.as_array((ctypes.c_float * B).from_address(values))[:] = np.asarray(v, np.float32).reshape(-1)
+            if len(book["out"]) >= 4:
+                return -7                                  # what the engine does with a fifth ticket: an error
+            book["next"] += 1
+            book["out"].add(book["next"])
+            book["max_out"] = max(book["max_out"], len(book["out"]))
+            return book["next"]
+
+        def wait(_ctx, ticket):
+            book["waits"].append(int(ticket))
+            if ticket not in book["out"]:
+                book["double"] += 1
+                return -9                                  # "unknown or already-waited ticket"
+            book["out"].discard(ticket)
+            return -5 if fail_wait_at is not None and len(book["waits"]) == fail_wait_at else 0
+
+        ev = selfplay.EvaluatorStruct(None, selfplay._SUBMIT_FN(submit), selfplay._WAIT_FN(wait))
+        pools = [selfplay.GamePool([100 + g for g in range(12) if g % n_pools == i], prm, cap=300, threads=1) for i in range(n_pools)]
+        handles = (ctypes.c_void_p * n_pools)(*[q._h for q in pools])
+        info = selfplay.RunInfo()
+        rc = lib.bk_pools_run(handles, n_pools, ctypes.byref(ev), 300, ctypes.byref(info))
+        games = {100 + g: pools[g % n_pools].moves(g // n_pools) for g in range(12)} if rc == 0 else None
+        return rc, book, games
+
+    rc2, book2, games2 = run(2)
+    rc6, book6, games6 = run(6)
+    assert rc2 == 0 and rc6 == 0 and games6 == games2
+    assert book2["max_out"] == 2 and book6["max_out"] == 4
+    for b in (book2, book6):
+        assert not b["out"] and b["double"] == 0 and len(set(b["waits"])) == len(b["waits"])
+    rc, book, _ = run(6, fail_wait_at=9)
+    assert rc == -5                                        # the evaluator's own code, not the second wait's
+    assert book["double"] == 0 and not book["out"] and len(set(book["waits"])) == len(book["waits"])
+
+
+def test_the_lanes_switch_of_a_pool_changes_nothing_but_who_works_on_a_game():
+    """bk_pool_set_lanes (what the environment variable BK_NO_LANES selected until round 5): games handed to the worker threads
+    from one counter instead of staying in their lanes -- the same games, the same counts."""
+    f = FakeNets()
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    prm = selfplay.search_params(rollouts=30, expand_thresh=5, noise_weight=0.25, sample_plies=2, max_turns=9, eager_top=4)
+    runs = []
+    for lanes in (True, False):
+        pool = selfplay.GamePool(list(range(200, 240)), prm, cap=4096, threads=3)
+        pool.set_lanes(lanes)
+        selfplay.run_pools([pool], ev)
+        runs.append([(pool.moves(g), pool.info(g)["score"], pool.info(g)["n_value_evals"]) for g in range(40)])
+    assert runs[0] == runs[1]
 
 
 def test_normalise_rows_is_categoricals_division():
