@@ -1264,7 +1264,8 @@ int bk_engine_set_option(bk_engine* e, const char* name, int value) {
     else if (n == "coop") ok = one_of({-1, 0, 2, 3, 4, 6, 8, 12});
     else if (n == "coop3") ok = one_of({-1, 0, 2, 4, 8});
     else if (n == "copy_threads") ok = value >= 0 && value <= 64;
-    else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap, the test hooks
+    else if (n == "coop_fault" || n == "fault_submit") ok = value >= 0;   // (test builds: fault_submit = the HIP call of a submission that fails)
+    else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap
     if (!ok) return fail(e, BK_ERR_ARG, std::string("engine option '") + name + "': value " + std::to_string(value) + " out of range");
     for (const auto& sl : e->slots)
         if (sl.busy && (n == "coop" || n == "coop3" || n == "force_nb" || n == "no_split"))

@@ -177,7 +177,7 @@ def test_config3_whole_game_matches_reference_on_both_trees(sds):
     out = os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     if os.path.isdir(out):
-        with open(os.path.join(out, "r05_cfg2_whole_game.json"), "w") as f:
+        with open(os.path.join(out, "cfg2_whole_game.json"), "w") as f:
             json.dump({"moves": 81, "rollouts": 1600, "python_tree_ms_per_move": ms_py, "native_tree_ms_per_move": ms_nat,
                        "native_requests_per_move": gi["n_requests"] / 81, "native_value_rows_per_move": gi["n_value_evals"] / 81,
                        "identical_to_reference": True}, f)

@@ -104,7 +104,7 @@ def test_config4_whole_games_equal_the_cpu_oracle_run(generation, sds):
     visit count of every ply must equal the GPU run's.  The two sides' network outputs differ by ~3e-5, so a PUCT near-tie
     may resolve the other way round: at least 30 of the 32 games must be identical, and where one is not, its first
     divergent ply must be a visit tie within 1 (one rollout gone to a sibling).  The figures go to
-    gpurun_out/r05_cfg3_oracle_depth.json (committed under profiles/)."""
+    gpurun_out/cfg3_oracle_depth.json (committed under profiles/)."""
     import time
     from oracle.oracle import OraclePolicy, OracleValue, set_threads
     set_threads(min(16, len(os.sched_getaffinity(0))))
@@ -138,7 +138,7 @@ def test_config4_whole_games_equal_the_cpu_oracle_run(generation, sds):
            "oracle_seconds": secs, "oracle_positions": ev.positions, "oracle_threads": min(16, len(os.sched_getaffinity(0)))}
     out = os.path.join(REPO, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r05_cfg3_oracle_depth.json"), "w") as f:
+    with open(os.path.join(out, "cfg3_oracle_depth.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print("\ncfg[3] oracle depth:", {k: v for k, v in rec.items() if k != "diverged"}, diverged)
     pool.close()
