@@ -268,7 +268,7 @@ void features_impl(bk_pos* p, O* out, int fresh) {
 
 extern "C" {
 
-int bk_go_abi_version(void) { return 5; }  // 5: bk_pool_game_stats, bk_pool_snapshot / _restore, bk_pools_run, bk_normalise_rows; 4: bk_search_params.simulate/use_value/value_weight, bk_pool_node_q, bk_pos_possible_eye; 3: bk_search_params.branch_num, bk_pool_set_dedup, bk_team_selftest_concurrent; 2: request_tasks, eager_top, request_steps, tree views
+int bk_go_abi_version(void) { return 6; }  // 6: bk_pool_set_lanes, BK_POOLS_MAX_INFLIGHT; 5: bk_pool_game_stats, bk_pool_snapshot / _restore, bk_pools_run, bk_normalise_rows; 4: bk_search_params.simulate/use_value/value_weight, bk_pool_node_q, bk_pos_possible_eye; 3: bk_search_params.branch_num, bk_pool_set_dedup, bk_team_selftest_concurrent; 2: request_tasks, eager_top, request_steps, tree views
 
 void bk_pos_init(bk_pos* p) {
     std::memset(p, 0, sizeof(*p));

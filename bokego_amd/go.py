@@ -53,7 +53,7 @@ GO_SYMBOLS = {
 _golib = None
 
 
-GO_ABI_VERSION = 5     # include/bokego_go.h + bokego_tree.h (bk_go_abi_version)
+GO_ABI_VERSION = 6     # include/bokego_go.h + bokego_tree.h (bk_go_abi_version)
 
 
 def golib():
