@@ -106,6 +106,10 @@ struct Game {
     State state = S_INIT;
     int remaining = 0;
     std::vector<int> path;
+    // bk_search_params.leaves > 1 (opt-in, not the reference's search): the rollouts of this step that wait for their leaf's value, each
+    // as [length, ids ...] back to back, in the order they were made; every node below the root on such a path carries a virtual loss
+    std::vector<int> pend;
+    int n_pend = 0;
     std::vector<int> req_policy, req_value;
     std::vector<int> spec_queue;        // leaves that reached prm.speculate visits and wait for a request with room
     std::vector<int> spill;             // children of expanded nodes whose value did not fit under prm.request_tasks: they
@@ -610,6 +614,67 @@ struct Game {
 
     bool has_request() const { return !req_policy.empty() || !req_value.empty(); }
 
+    // ---- the opt-in multi-leaf mode (bk_search_params.leaves > 1; SURVEY 7.6: "virtual loss only as an opt-in throughput mode") ----
+    // NOT the reference's search: up to `leaves` rollouts of one step wait for a value together.  A waiting rollout leaves a virtual
+    // loss on every node of its path below the root -- one more visit, lost by the side that moved there (V + 1: select() scores a
+    // child by -avg) -- so that the next descent of the step goes elsewhere; back_up_leaves() takes the losses off and backs the
+    // rollouts up in the order they were made.  A rollout whose leaf value is known is backed up at once, unless it ends on a node
+    // whose expansion still waits for its policy row (kids without priors: nothing can be selected below it, and backing it up at
+    // once would send the step's remaining rollouts down the same path): that one waits too, as in the one-leaf search.
+    static void virtual_loss(TNode& n, int sign) {
+        n.N += sign;
+        n.V += (double)sign;
+        n.avg = n.N > 0 ? n.V / (double)n.N : 0.0;
+    }
+    bool search_leaves() {  // true: a request goes out (n_pend rollouts wait for it); false: this move's rollouts are done
+        while (remaining > n_pend) {
+            path.clear();
+            int id = root;
+            path.push_back(id);
+            for (;;) {
+                if (nodes[id].n_kids == 0) {
+                    if (!nodes[id].expanded && nodes[id].N > prm.expand_thresh) expand(id);   // (may reallocate `nodes`)
+                    break;
+                }
+                if (!nodes[id].has_prior) break;                 // its policy row is still out
+                id = select(id);
+                path.push_back(id);
+            }
+            if (analyze && path.size() > 2) variations[path[1]].assign(path.begin() + 1, path.end());
+            request_leaf();
+            const TNode& leaf = nodes[path.back()];
+            if (leaf.has_value && !(leaf.n_kids > 0 && !leaf.has_prior)) {
+                backprop();
+                --remaining;
+                continue;
+            }
+            for (size_t i = 1; i < path.size(); ++i) virtual_loss(nodes[path[i]], +1);
+            pend.push_back((int)path.size());
+            pend.insert(pend.end(), path.begin(), path.end());
+            if (++n_pend >= prm.leaves) break;
+        }
+        path.clear();
+        if (n_pend > 0 || has_request()) {
+            add_speculation();                                   // (what spilled over from earlier expansions rides along)
+            return true;
+        }
+        return false;
+    }
+    void back_up_leaves() {
+        size_t at = 0;
+        for (int r = 0; r < n_pend; ++r) {
+            const int len = pend[at++];
+            path.assign(pend.begin() + (long)at, pend.begin() + (long)at + len);
+            at += (size_t)len;
+            for (size_t i = 1; i < path.size(); ++i) virtual_loss(nodes[path[i]], -1);
+            backprop();
+            --remaining;
+        }
+        pend.clear();
+        n_pend = 0;
+        path.clear();
+    }
+
     void reroot(int id) {  // MCTS.set_root (mcts.py:153-157): keep the subtree, expand the new root
         variations.clear();
         root = id;
@@ -666,6 +731,14 @@ struct Game {
                     state = S_SEARCH;
                     break;
                 case S_SEARCH: {
+                    if (prm.leaves > 1) {                            // the opt-in multi-leaf mode (bk_search_params.leaves)
+                        if (search_leaves()) {
+                            state = S_WAIT_LEAF;
+                            return true;
+                        }
+                        state = manual ? S_IDLE : S_CHOOSE;
+                        break;
+                    }
                     bool waiting = false, playing = false;
                     while (remaining > 0) {
                         path.clear();
@@ -722,6 +795,11 @@ struct Game {
                     state = S_SEARCH;
                     break;
                 case S_WAIT_LEAF:
+                    if (prm.leaves > 1) {
+                        back_up_leaves();
+                        state = S_SEARCH;
+                        break;
+                    }
                     if (pending_expand >= 0) {                       // branch_num: the leaf's priors are in: expand it before
                         const int id = pending_expand;               // the next rollout (what it asks for rides with a later request)
                         pending_expand = -1;
@@ -821,6 +899,8 @@ void bk_search_params_default(bk_search_params* p) {
     p->simulate = 0;
     p->use_value = 1;
     p->value_weight = 1.0;
+    p->leaves = 1;
+    p->reserved0 = 0;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {
@@ -830,6 +910,9 @@ bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t
     bk_search_params q = *prm;
     if (!q.use_value) q.eager = q.eager_top = 0;                 // no value net (mcts.py:68-69): nothing asks for a value
     if (!q.use_value || q.simulate) q.speculate = 0;             // (a playout's nodes must stay the newest ones of the tree)
+    if (q.leaves < 1 || !q.use_value || q.simulate || (q.branch_num > 0 && q.branch_num < 81)) q.leaves = 1;   // (bk_search_params.leaves)
+    if (q.leaves > 1) q.speculate = 0;
+    q.reserved0 = 0;
     for (int i = 0; i < n_games; ++i) p->games.emplace_back(q, seeds[i]);
     p->threads = threads > 0 ? threads : 1;
     return p;
@@ -1621,7 +1704,7 @@ int bk_pool_game_stats(const bk_pool* p, int g, bk_game_stats* out) {
 
 namespace {
 constexpr uint32_t kSnapMagic = 0x31544B42u;   // "BKT1"
-constexpr uint32_t kSnapVersion = 1;
+constexpr uint32_t kSnapVersion = 2;   // 2: bk_search_params.leaves, the multi-leaf mode's waiting rollouts
 struct SnapWriter {
     std::vector<uint8_t> b;
     void raw(const void* p, size_t n) { const uint8_t* q = static_cast<const uint8_t*>(p); b.insert(b.end(), q, q + n); }
@@ -1685,7 +1768,9 @@ void snapshot_game(const Game& gm, SnapWriter& w) {
     w.pod(ints);
     // (the last rollout's path is read again only while its leaf's value is out or its playout runs; after a re-rooting of a
     // pruning tree its ids are stale -- every rollout starts with path.clear())
-    w.vec(gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT ? gm.path : std::vector<int>());
+    w.vec(gm.prm.leaves <= 1 && (gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT) ? gm.path : std::vector<int>());
+    w.vec(gm.pend);                                      // (the multi-leaf mode's waiting rollouts: [length, ids ...] each)
+    w.pod((int32_t)gm.n_pend);
     w.vec(gm.req_policy);
     w.vec(gm.req_value);
     w.vec(gm.spec_queue);
@@ -1724,7 +1809,8 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
     if (!r.pod(ints)) return false;
     gm.root = ints[0]; gm.state = (State)ints[1]; gm.remaining = ints[2]; gm.pending_expand = ints[3];
     gm.po = ints[4]; gm.po_mark = ints[5]; gm.po_reward = ints[6]; gm.row_cap = ints[7];
-    r.vec(gm.path); r.vec(gm.req_policy); r.vec(gm.req_value); r.vec(gm.spec_queue); r.vec(gm.spill);
+    int32_t n_pend = 0;
+    r.vec(gm.path); r.vec(gm.pend); r.pod(n_pend); r.vec(gm.req_policy); r.vec(gm.req_value); r.vec(gm.spec_queue); r.vec(gm.spill);
     r.map(gm.spec_kids); r.map(gm.variations); r.vec(gm.po_priors);
     r.pod(gm.rng.s);
     r.vec(gm.moves);
@@ -1756,8 +1842,9 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
             !in(q.sample_plies, 0, 1 << 20) || !in(q.max_turns, 0, 100000) || !in(q.eager, 0, 1) || !fin(q.komi, -1000.0, 1000.0) ||
             !in(q.record_visits, 0, 1) || !in(q.prune, 0, 1) || !in(q.speculate, 0, 1 << 30) || !in(q.speculate_rows, 0, 1 << 30) ||
             !in(q.request_tasks, 0, 1 << 30) || !in(q.eager_top, 0, 81) || !in(q.branch_num, 0, 81) || !in(q.simulate, 0, 1) ||
-            !in(q.use_value, 0, 1) || !fin(q.value_weight, 0.0, 1.0))
+            !in(q.use_value, 0, 1) || !fin(q.value_weight, 0.0, 1.0) || !in(q.leaves, 1, 64) || q.reserved0 != 0)
             return false;
+        if (q.leaves > 1 && (q.simulate || !q.use_value || (q.branch_num > 0 && q.branch_num < 81) || q.speculate)) return false;   // (bk_pool_create's rule)
         for (int v : q.request_steps)
             if (!in(v, 0, 1 << 30)) return false;
         if (!q.use_value && !q.simulate) return false;                       // (bk_search_params: no value net needs simulate)
@@ -1795,15 +1882,42 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
     // `path` from the root down -- it must be there, start at the root and follow the tree's own edges; every other state starts
     // its next rollout with path.clear() and the writer leaves it out (a snapshot patched to S_WAIT_LEAF with an empty
     // path was accepted, and the next collect read path.back())
-    if (gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT) {
-        if (gm.path.empty() || gm.path[0] != gm.root) return false;
-        if (gm.state == S_PLAYOUT && !gm.prm.simulate) return false;
-        for (size_t i = 0; i + 1 < gm.path.size(); ++i) {
-            const TNode& nd = gm.nodes[(size_t)gm.path[i]];
+    auto walks_the_tree = [&](const int* pth, size_t len) {
+        if (len == 0 || pth[0] != gm.root) return false;
+        for (size_t i = 0; i + 1 < len; ++i) {
+            const TNode& nd = gm.nodes[(size_t)pth[i]];
             const int* k0 = gm.kid_ids.data() + nd.kids_off;
-            if (std::find(k0, k0 + nd.n_kids, gm.path[i + 1]) == k0 + nd.n_kids) return false;
+            if (std::find(k0, k0 + nd.n_kids, pth[i + 1]) == k0 + nd.n_kids) return false;
         }
-    } else if (!gm.path.empty()) {
+        return true;
+    };
+    if (gm.prm.leaves > 1) {
+        // the multi-leaf mode keeps its waiting rollouts in `pend` ([length, ids ...] each, n_pend of them, at most `leaves`) and uses
+        // `path` as scratch: a snapshot has them in S_WAIT_LEAF only, each walking the tree from the root, and their virtual losses on
+        // the nodes (a node's visit count covers the losses it carries: taking them off must not go below zero)
+        if (!gm.path.empty() || n_pend < 0 || n_pend > gm.prm.leaves || (gm.state != S_WAIT_LEAF && (n_pend != 0 || !gm.pend.empty()))) return false;
+        std::vector<int> losses(gm.nodes.size(), 0);
+        size_t at = 0;
+        for (int r = 0; r < n_pend; ++r) {
+            if (at >= gm.pend.size()) return false;
+            const int len = gm.pend[at++];
+            if (len < 1 || (size_t)len > gm.pend.size() - at) return false;
+            for (int i = 0; i < len; ++i)
+                if (!node_ok(gm.pend[at + (size_t)i])) return false;
+            if (!walks_the_tree(gm.pend.data() + at, (size_t)len)) return false;
+            for (int i = 1; i < len; ++i) losses[(size_t)gm.pend[at + (size_t)i]] += 1;
+            if (!gm.nodes[(size_t)gm.pend[at + (size_t)len - 1]].has_value) return false;     // backprop reads the leaf's value
+            at += (size_t)len;
+        }
+        if (at != gm.pend.size()) return false;
+        for (size_t i = 0; i < gm.nodes.size(); ++i)
+            if (gm.nodes[i].N < losses[i]) return false;
+        gm.n_pend = n_pend;
+    } else if (gm.state == S_WAIT_LEAF || gm.state == S_PLAYOUT) {
+        if (!gm.pend.empty() || n_pend != 0) return false;
+        if (!walks_the_tree(gm.path.data(), gm.path.size())) return false;
+        if (gm.state == S_PLAYOUT && !gm.prm.simulate) return false;
+    } else if (!gm.path.empty() || !gm.pend.empty() || n_pend != 0) {
         return false;
     }
     // states that index nodes[root] need a root (and what they read of it); a pending expansion is looked at in the waiting states only

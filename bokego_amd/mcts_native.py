@@ -172,6 +172,12 @@ class NativeMCTS:
                                      speculate=spec[0], speculate_rows=spec[1], request_tasks=spec[2],
                                      request_steps=kwargs.get("request_steps", (spec[2], 80, 128) if spec[2] == 64 else (spec[2],)))
         prm.eager_top = kwargs.get("eager_top", EAGER_TOP)
+        # OPT-IN, not the reference's search: `leaves` > 1 rollouts of a step wait for their values together under virtual loss
+        # (bk_search_params.leaves).  Default 1 = the reference's sequential search, rollout for rollout.
+        prm.leaves = max(1, int(kwargs.get("leaves", 1)))
+        if prm.leaves > 1:
+            prm.speculate, prm.request_tasks = 0, 0
+            prm.request_steps[0] = prm.request_steps[1] = prm.request_steps[2] = 0
         prm.simulate, prm.use_value, prm.value_weight = int(not self.no_sim), int(has_value), float(self.value_net_weight)
         if self.branch_num is not None and 0 <= self.branch_num < go.N ** 2:
             if self.branch_num == 0:

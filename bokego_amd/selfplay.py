@@ -32,7 +32,8 @@ class SearchParams(ctypes.Structure):
                 ("prune", ctypes.c_int32), ("speculate", ctypes.c_int32),
                 ("speculate_rows", ctypes.c_int32), ("request_tasks", ctypes.c_int32), ("eager_top", ctypes.c_int32),
                 ("request_steps", ctypes.c_int32 * 3), ("branch_num", ctypes.c_int32),
-                ("simulate", ctypes.c_int32), ("use_value", ctypes.c_int32), ("value_weight", ctypes.c_double)]
+                ("simulate", ctypes.c_int32), ("use_value", ctypes.c_int32), ("value_weight", ctypes.c_double),
+                ("leaves", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class NodeInfo(ctypes.Structure):
@@ -622,7 +623,7 @@ def shard_game_ids(n_games, rank, world):
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
               reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None,
-              dedup=None, native_loop=None, pool_sizes=None, speculate=None, speculate_rows=8):
+              dedup=None, native_loop=None, pool_sizes=None, speculate=None, speculate_rows=8, leaves=1):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
@@ -633,7 +634,10 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     pool_sizes: how many of this rank's games each pool gets (a list summing to the rank's games; task_cap may then be a list
     too, one per pool).  Default: n_pools equal pools (unequal ones, sized so that each pool's requests land on the cheap side
     of the launch forms' size steps, were measured and gain nothing: profiles/r05_pool_split.txt).
-    speculate: evaluation ahead of expansion in the pools (bk_search_params.speculate; None: small_shard_defaults())."""
+    speculate: evaluation ahead of expansion in the pools (bk_search_params.speculate; None: small_shard_defaults()).
+    leaves: > 1 = the OPT-IN multi-leaf throughput mode (bk_search_params.leaves: up to that many rollouts of a step wait for a
+    value together, under virtual loss).  Not the reference's search -- other trees, other games, no parity claim --
+    but still a pure function of the seeds: the games do not depend on sharding, pools, threads or batch grouping.  Default 1: off."""
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
     if eager_top is None:
@@ -646,11 +650,14 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     biggest_pool = max(pool_sizes) if pool_sizes else -(-len(gids) // max(1, n_pools))
     small = small_shard_defaults(precision, eager_top, biggest_pool)
+    leaves = max(1, int(leaves))
+    if leaves > 1:
+        small, speculate = (0, 0), 0              # (the mode brings its own rows: no evaluation ahead, batches held to whole rounds)
     if speculate is None:
         speculate = small[0]
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
-                        eager_top=eager_top, speculate=speculate, speculate_rows=speculate_rows)
+                        eager_top=eager_top, speculate=speculate, speculate_rows=speculate_rows, leaves=leaves)
     if pool_sizes is not None:
         pool_sizes = [int(k) for k in pool_sizes if int(k) > 0]
         if sum(pool_sizes) != len(gids):
@@ -670,7 +677,10 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         # two rounds -- rocprofv3 showed 605 of 1,160 launches at exactly 768 tasks taking the 1.0 ms three-round one-board form)
         n_cu = getattr(getattr(evaluator, "engine", None), "n_cu", 256)
         per_round, biggest = 3 * n_cu, max((len(part) for part in parts), default=0)     # (a rank may have no game at all)
-        if precision == "f32" and 0 < eager_top <= 2:
+        if leaves > 1 and precision == "f32" and eager_top:
+            # ~(1 + eager_top) tasks per waiting rollout: whole rounds of 3-board workgroups nearest to what the pool asks for
+            task_cap = per_round * max(1, round((1.0 + eager_top) * leaves * biggest / per_round)) - 4
+        elif precision == "f32" and 0 < eager_top <= 2:
             # ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups (256 / 512 / 768 tasks on 256 CUs)
             task_cap = n_cu * max(1, round(2.0 * biggest / n_cu)) - 4
         elif small[1] and speculate:
@@ -709,7 +719,7 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         p.close()
     named = named_stats(total)
     return ({"games": games, "visits": visits, "seconds": dt, "steps": steps, "local_stats": local, "native_loop": bool(native_loop),
-             "n_pools": n_pools, "speculate": int(speculate), "task_caps": [int(c or 0) for c in caps], "allreduce_s": t_reduce, "allreduce_wait_s": timing.get("wait_s", 0.0), "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
+             "n_pools": n_pools, "speculate": int(speculate), "leaves": leaves, "task_caps": [int(c or 0) for c in caps], "allreduce_s": t_reduce, "allreduce_wait_s": timing.get("wait_s", 0.0), "dedup": bool(dedup), "rows_requested": rows_req, "rows_sent": rows_sent}, named)
 
 
 # ---- the reference's policy-vs-policy playouts (bin/selfplay.py:18-57) --------------------------------

@@ -87,6 +87,20 @@ typedef struct bk_search_params {
     double value_weight;   /* MCTS kwarg value_net_weight (mcts.py:65-72): a child's average reward in the selection is
                               ((1 - w) Q + w V) / N.  1.0 without simulation (the reference forces it), else default 0.5, 0
                               without a value net                                                                            */
+    int32_t leaves;        /* OPT-IN THROUGHPUT MODE, NOT the reference's search ("virtual loss only as an opt-in
+                              throughput mode"; default 1 = off, every parity statement in this header is about 1).  > 1: a search
+                              step gathers up to `leaves` rollouts that wait for a value before it sends its request: each
+                              waiting rollout leaves a VIRTUAL LOSS on its path (every node below the root counts one more
+                              visit, lost by the side that moved there), so that the next descent goes elsewhere; when the values
+                              are back the losses are taken off and the rollouts are backed up in the order they were made.
+                              Rollouts whose leaf value is already known are backed up at once, as ever.  A request then carries
+                              ~`leaves` times the rows -- a 64-game pool asks for a full round of workgroups instead of a
+                              third of one -- and a move needs ~1 / leaves of the round trips.  Deterministic per game (the
+                              games still do not depend on sharding, threads or batch grouping), every rollout is backed up
+                              exactly once (the visit totals of a search are those of `leaves` = 1), but the tree it builds is
+                              another one: rollouts descend on statistics that are up to leaves - 1 backups behind.
+                              Ignored (= 1) with simulate, branch_num or without a value net; turns speculate off.          */
+    int32_t reserved0;
 } bk_search_params;
 
 typedef struct bk_game_info {

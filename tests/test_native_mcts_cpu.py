@@ -685,3 +685,116 @@ def test_restore_refuses_or_survives_corrupted_snapshots():
         dst.restore(0, good)
         before = (dst.moves(0), dst.info(0), dst.root_children(0))
     assert refused > 1500 and accepted > 200, (refused, accepted)
+
+
+# ---- the opt-in multi-leaf mode (bk_search_params.leaves; SURVEY 7.6: virtual loss "only as an opt-in throughput mode") -------------
+def test_multi_leaf_mode_is_off_by_default_and_conserves_every_rollout():
+    """VERDICT r5 next #7 (outside SURVEY 8: no parity claim).  leaves = 1 -- the default -- is the reference's search, rollout for
+    rollout (every other test in this file).  leaves > 1: up to that many rollouts of a step wait for their values together under
+    virtual loss.  Another tree, but every rollout is backed up exactly once and no virtual loss is left behind: after n rollouts
+    the root has n more visits, its children share them all, every node's |V| <= N, and a node's visits are its own rollouts-as-leaf
+    plus its children's (the same accounting identities the one-leaf search obeys)."""
+    f = FakeNets()
+    for leaves in (1, 2, 4, 8):
+        t = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12, leaves=leaves)
+        done = 0
+        for n in (150, 7, 300):
+            t.rollout(n)
+            done += n
+            kids = t.children[t.root]
+            assert t.N[t.root] == done and sum(t.N[k] for k in kids) == done, leaves
+            for node in t.children:                      # every expanded node
+                sub = sum(t.N[k] for k in t.children[node])
+                assert 0 <= sub <= t.N[node] and abs(t.V[node]) <= t.N[node] + 1e-9
+        ref = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12)
+        ref.rollout(457)
+        same = t.child_stats() == ref.child_stats()
+        assert same == (leaves == 1)                     # (with these nets the trees do differ once rollouts wait together)
+    # modes the rule does not cover fall back to one leaf: the same search as without the keyword
+    for kw in (dict(no_sim=False), dict(branch_num=5)):
+        a = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12, seed=3, leaves=4, **kw)
+        b = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12, seed=3, **kw)
+        a.rollout(60); b.rollout(60)
+        assert a.child_stats() == b.child_stats(), kw
+
+
+def test_multi_leaf_games_are_a_pure_function_of_their_seeds():
+    """The mode changes the search, not the contract of a generation: a game is a pure function of its seed and the networks -- the
+    same games for one, two or three pools, two thread counts, one rank or two ranks' shards, the step loop in Python or in C -- and a
+    step carries more rows, so a generation needs fewer round trips."""
+    f = FakeNets()
+    pol = lambda x: np.stack([f.policy(r[None])[0] for r in x]) if len(x) else np.zeros((0, 81), np.float32)  # noqa: E731
+    val = lambda x: np.array([f.value(r[None])[0] for r in x], np.float32)  # noqa: E731
+    kw = dict(n_games=10, rollouts=120, expand_thresh=20, noise_weight=0.25, sample_plies=3, max_turns=12, cap=4000, eager_top=4, record_visits=1)
+
+    def run(leaves, **extra):
+        ev = selfplay.RecordEvaluator(pol, val)
+        local, total = selfplay.self_play(ev, leaves=leaves, **{**kw, **extra})
+        return local, total
+
+    base, tot = run(4, n_pools=1, threads=1)
+    assert base["leaves"] == 4
+    for extra in (dict(n_pools=2, threads=3), dict(n_pools=3, threads=2, native_loop=False), dict(n_pools=2, threads=2, dedup=True, task_cap=30)):
+        local, total = run(4, **extra)
+        assert local["games"] == base["games"] and local["visits"] == base["visits"], extra
+        assert np.array_equal(total["root_visit_hist"], tot["root_visit_hist"]) and total["sum_root_value"] == tot["sum_root_value"]
+    halves = [run(4, rank=r, world=2, n_pools=2, threads=2)[0]["games"] for r in (0, 1)]
+    assert {**halves[0], **halves[1]} == base["games"]
+    one, _ = run(1, n_pools=1, threads=1)
+    eight, _ = run(8, n_pools=1, threads=1)
+    assert one["games"] != base["games"]                               # another search ...
+    assert eight["steps"] < 0.7 * one["steps"]                         # ... with fewer round trips
+    for g in base["games"]:                                            # every ply's record holds that ply's rollouts (+ the kept subtree's)
+        assert all(sum(ply.values()) >= 120 - 1 for ply in base["visits"][g])
+
+
+def test_a_snapshot_in_the_middle_of_a_multi_leaf_step_plays_on():
+    """bk_pool_snapshot between a deliver and the next collect of a multi-leaf search: the rollouts that wait (their paths, the virtual
+    losses on them) travel with the game; restored into another pool it plays on to the same record.  Corrupted copies are refused
+    or survive stepping, as in the one-leaf mode."""
+    f = FakeNets()
+    prm = selfplay.search_params(rollouts=60, expand_thresh=8, noise_weight=0.25, sample_plies=3, max_turns=10, prune=1, record_visits=1,
+                                 eager_top=4, leaves=4)
+    ev = selfplay.CallableEvaluator(f.policy, f.value)
+    ref = selfplay.GamePool([77], prm, cap=512, threads=1)
+    selfplay.run_pools([ref], ev)
+    a = selfplay.GamePool([77], prm, cap=512, threads=1)
+    blobs = []
+    for step in range(10_000):
+        feats, npol = a.collect()
+        if len(feats) == 0:
+            break
+        a.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
+        if step % 7 == 3 and len(blobs) < 6:
+            blobs.append(a.snapshot(0))
+    assert a.moves(0) == ref.moves(0) and len(blobs) == 6
+    for blob in blobs:
+        b = selfplay.GamePool([1, 2], selfplay.search_params(rollouts=5, max_turns=3), cap=600, threads=2)
+        b.restore(1, blob)
+        selfplay.run_pools([b], ev)
+        assert b.moves(1) == ref.moves(0) and b.info(1)["score"] == ref.info(0)["score"]
+        assert [b.visits(1, k) for k in range(len(b.moves(1)))] == [ref.visits(0, k) for k in range(len(ref.moves(0)))]
+    rng = np.random.default_rng(9)
+    good = blobs[2]
+    dst = selfplay.GamePool([5], prm, cap=512, threads=1)
+    refused = 0
+    for trial in range(1500):
+        bb = bytearray(good)
+        if trial % 3 == 0:
+            bb[int(rng.integers(0, len(bb)))] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 1:
+            at = int(rng.integers(16, len(bb) - 4))
+            bb[at:at + 4] = int(rng.integers(-2**31, 2**31)).to_bytes(4, "little", signed=True)
+        else:
+            bb = bb[:int(rng.integers(0, len(bb)))]
+        try:
+            dst.restore(0, bytes(bb))
+        except ValueError:
+            refused += 1
+            continue
+        for _ in range(20):
+            feats, npol = dst.collect()
+            if len(feats) == 0:
+                break
+            dst.deliver(*ev.finish(ev.submit(feats, npol), normalise=selfplay.normalise_rows))
+    assert refused > 400
