@@ -322,3 +322,25 @@ def test_a_ranks_share_at_eight_ranks_plays_its_games_with_evaluation_ahead(engi
     assert sorted(on["games"]) == gids and on["games"] == off["games"] == {g: local["games"][g] for g in gids}
     assert on["visits"] == off["visits"] == {g: local["visits"][g] for g in gids}
     assert on["steps"] < off["steps"]
+
+
+def test_the_opt_in_multi_leaf_mode_on_the_engine(engine, generation):
+    """bk_search_params.leaves (virtual loss only as an opt-in throughput mode; outside SURVEY 8, no parity claim): a rank's
+    64-game share of configs[3] with 8 leaves per tree and step on the real path.  Still a pure function of the seeds -- the same games
+    for another pool split, the step loop in Python, and as two half-shards -- with fewer, larger requests than the one-leaf search,
+    every ply's record holding that ply's 400 rollouts; and the default (leaves = 1) is untouched: the `generation` fixture's games."""
+    kw = dict(n_games=512, rollouts=400, cap=8192, rank=0, world=8, record_visits=1)
+    one, _ = selfplay.self_play(selfplay.EngineEvaluator(engine), **kw)
+    assert one["leaves"] == 1 and all(one["games"][g] == generation[0]["games"][g] for g in one["games"])
+    base, tot = selfplay.self_play(selfplay.EngineEvaluator(engine), leaves=8, **kw)
+    assert base["leaves"] == 8 and base["games"] != one["games"]
+    assert base["steps"] < 0.75 * one["steps"] and base["rows_sent"] / base["steps"] > 1.2 * one["rows_sent"] / one["steps"]
+    for extra in (dict(n_pools=3), dict(native_loop=False, threads=2)):
+        loc, t2 = selfplay.self_play(selfplay.EngineEvaluator(engine), leaves=8, **kw, **extra)
+        assert loc["games"] == base["games"] and loc["visits"] == base["visits"] and t2["root_visit_hist"] == tot["root_visit_hist"], extra
+    halves = {}
+    for r in (0, 8):                                   # ranks 0 and 8 of a world of 16 = the two halves of rank 0's share of 8
+        loc, _ = selfplay.self_play(selfplay.EngineEvaluator(engine), leaves=8, n_games=512, rollouts=400, cap=8192, rank=r, world=16)
+        halves.update(loc["games"])
+    assert halves == base["games"]
+    assert all(sum(ply.values()) >= 399 for plies in base["visits"].values() for ply in plies)

@@ -21,7 +21,7 @@ if "--match-only" not in sys.argv:
     selfplay.self_play(ev, n_games=64, rollouts=50, cap=8192)
     for world, threads in ((8, 4), (4, 4), (1, 12)) if not quick else ((8, 4),):
         games = {}
-        for leaves in (1, 2, 4, 8):
+        for leaves in (1, 2, 4, 8, 16, 32):
             best = None
             for _ in range(3):
                 local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=0, world=world, cap=8192, threads=threads, leaves=leaves)
@@ -40,7 +40,7 @@ if "--no-match" not in sys.argv:
     pw, vw = load_bkw(os.path.join(g, "policy_19.bkw")), load_bkw(os.path.join(g, "value_synth.bkw"))
     pi, val = nnet.HipPolicyNet(pw), nnet.HipValueNet(vw)
     n_games = 20 if quick else 100
-    for leaves, rollouts in ((4, 1600), (8, 1600), (8, 400)) if not quick else ((4, 400),):
+    for leaves, rollouts in ((8, 1600), (16, 1600), (8, 400), (16, 400), (32, 400)) if not quick else ((4, 400),):
         a = match.InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=rollouts, leaves=leaves), name=f"leaves{leaves}")
         b = match.InProcessEngine(NativeGTP(Position(), pi, val, no_sim=True, time_lim=None, n_rollouts=rollouts), name="one_leaf")
         res = match.play_match(a, b, n_games, 5.5, None, opening_plies=4, seed=60_000)
