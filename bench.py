@@ -966,14 +966,14 @@ def main():
         selfplay.self_play(selfplay.EngineEvaluator(eng), n_games=min(64 * world, args.selfplay_games), rollouts=50, rank=rank, world=world,
                            cap=8192, threads=threads, reduce_device=red)
 
-        def generation(n_games, prec):
+        def generation(n_games, prec, leaves=1):
             """one generation of n_games games over all ranks: whole-job games/min (max over ranks), what each rank needed, the
             all-reduce, and the visit / value statistics it sums"""
             ev = selfplay.EngineEvaluator(eng)
             barrier()
             mine = len(selfplay.shard_game_ids(n_games, rank, world))
             local, total = selfplay.self_play(ev, n_games=n_games, rollouts=400, rank=rank, world=world, cap=8192, threads=threads_for(mine),
-                                              reduce_device=red)
+                                              reduce_device=red, leaves=leaves)
             per_rank_s = gather(local["seconds"])
             reduce_ms = gather(local["allreduce_s"] * 1e3)          # the collective alone (every rank waited at a barrier first) ...
             wait_ms = gather(local["allreduce_wait_s"] * 1e3)       # ... and that wait: how long before the slowest rank this one was done
@@ -1020,6 +1020,13 @@ def main():
             progress(f"self-play, strong leg, {prec}: {args.selfplay_games} games over {world} rank(s)")
             sp[prec] = generation(args.selfplay_games, prec)          # STRONG scaling: the config's fixed 512 games over all ranks
         eng.set_precision(args.precision)
+        # OPT-IN, labelled, never the leg the line's games_per_min is: the multi-leaf throughput mode (bk_search_params.leaves = 8: up
+        # to eight rollouts of a tree wait for their values together under virtual loss -- SURVEY 7.6 allows it "only as an opt-in
+        # throughput mode"; another search than the reference's, no parity claim).  What it buys grows as a rank's share shrinks.
+        progress(f"self-play, strong leg in the opt-in multi-leaf mode: {args.selfplay_games} games over {world} rank(s)")
+        sp["opt_in_multi_leaf"] = dict(generation(args.selfplay_games, args.precision, leaves=8), leaves=8, precision=args.precision,
+                                       what="NOT the reference's search (virtual loss, 8 leaves per tree and step; off by default): the strong leg's "
+                                            "games with fewer, larger requests; strength against the one-leaf search: profiles/r06_leaves_probe.txt")
         # WEAK scaling: every rank plays its own full set (what the reference's workers do: cpu_count() processes, each with
         # its own games, bin/selfplay.py:177-199) -- games x n_gpus in all, `games` per rank, the same one all-reduce at the
         # end.  At one rank it is the strong leg.  A rank's seconds here are what ONE rank needs for the whole config, so

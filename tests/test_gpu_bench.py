@@ -66,6 +66,9 @@ def test_bench_line_contract():
         assert 0.01 < ro["frac"] < 1.0 and len(ro["per_rank_frac"]) == 1 and 0.5 < ro["rows_sent_over_rows_requested"] <= 1.0
         assert g["stats_allreduce_ms"] == 0 and g["allreduce_wait_ms_per_rank"] == [0.0] and g["value_sums_exact"] is True
     assert d["selfplay"]["weak"]["same_as"] == "f32"
+    ml = d["selfplay"]["opt_in_multi_leaf"]      # labelled, beside the line's own leg: never what games_per_min reports
+    assert ml["leaves"] == 8 and "NOT the reference's search" in ml["what"] and ml["games"] == 64 and ml["roofline"]["frac"] > 0
+    assert d["selfplay"]["games_per_min"] == d["selfplay"]["f32"]["games_per_min"]
 
 
 def test_bench_starts_its_own_ranks():
