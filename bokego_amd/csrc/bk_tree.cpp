@@ -1807,6 +1807,7 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
     int32_t ints[8];
     r.vec(gm.nodes); r.vec(gm.poses); r.vec(gm.Qs); r.vec(gm.kid_ids); r.vec(gm.priors);
     if (!r.pod(ints)) return false;
+    if (ints[1] < (int32_t)S_INIT || ints[1] > (int32_t)S_IDLE) return false;          // (checked as an integer: an enum must not hold anything else)
     gm.root = ints[0]; gm.state = (State)ints[1]; gm.remaining = ints[2]; gm.pending_expand = ints[3];
     gm.po = ints[4]; gm.po_mark = ints[5]; gm.po_reward = ints[6]; gm.row_cap = ints[7];
     int32_t n_pend = 0;
@@ -1867,6 +1868,18 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
         if (!(q.last_move == BK_NO_MOVE || q.last_move == BK_PASS || (q.last_move >= 0 && q.last_move <= 80))) return false;
         if (gm.nodes[(size_t)i].mv != q.last_move) return false;      // intern(): a node is reached by its position's last move
     }
+    // the statistics the search and the end-of-generation sums compute with: visit counts that can be summed in an int, value sums
+    // no larger than the visits behind them (|value| <= 1 per backup; + the virtual losses of the multi-leaf mode), finite averages --
+    // a wild V would overflow the fixed-point root-value sums (UBSan on an accepted corruption, round 6)
+    for (const TNode& nd : gm.nodes) {
+        if (nd.N < 0 || nd.N > (1 << 28) || !(std::fabs(nd.V) <= (double)nd.N + 64.0) || !(std::fabs(nd.avg) <= 65.0) || !(std::fabs(nd.value) <= 1.0f)) return false;
+    }
+    if (gm.n_root_values > ((uint64_t)1 << 30) || std::llabs(gm.sum_root_value_q) > (long long)((gm.n_root_values + 1) << 32) ||
+        gm.sum_abs_root_value_q < 0 || gm.sum_abs_root_value_q > (long long)((gm.n_root_values + 1) << 32)) return false;
+    for (size_t i = 0; i < gm.Qs.size(); ++i)
+        if (!(std::fabs(gm.Qs[i]) <= (double)gm.nodes[i].N + 1.0)) return false;
+    for (double pr : gm.priors)
+        if (!(pr >= 0.0 && pr <= 1.0e6)) return false;
     for (const TNode& nd : gm.nodes) {
         if (nd.n_kids < 0 || nd.kids_off < 0 || (size_t)nd.kids_off + (size_t)nd.n_kids > gm.kid_ids.size()) return false;
         if (nd.has_prior && (nd.prior_off < 0 || (size_t)nd.prior_off + 81 > gm.priors.size())) return false;
