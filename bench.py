@@ -928,6 +928,11 @@ def main():
             two = kernel_us(90)
         eight = kernel_us(90)
         small["B90"] = {"two_cus_per_board_us": two[0], "three_boards_on_8_cus_us": eight[0], "cooperative_launches": eight[1], "fallbacks": eight[2]}
+        # the remaining forms of the planner, so that every one has a time in the line and a row in the rocprofv3 summary of this command
+        # (VERDICT r5 next #2a): 8 / 6 / 3 / 2 CUs per board
+        for B, key in ((20, "eight_cus_per_board_us"), (33, "six_cus_per_board_us"), (70, "three_cus_per_board_us"), (110, "two_cus_per_board_us")):
+            coop = kernel_us(B)
+            small[f"B{B}"] = {key: coop[0], "cooperative_launches": coop[1], "fallbacks": coop[2]}
         # how far each of these requests is from the fp32-MFMA roof (B ValueNet rows, the first of which also runs the PolicyNet: B + 1 network tasks of 133.4 MFLOP)
         for k, v in small.items():
             if k.startswith("B"):
