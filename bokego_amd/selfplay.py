@@ -640,8 +640,11 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     but still a pure function of the seeds: the games do not depend on sharding, pools, threads or batch grouping.  Default 1: off."""
     gids = shard_game_ids(n_games, rank, world) if gids is None else [int(g) for g in gids]
     precision = getattr(getattr(evaluator, "engine", None), "precision", "f16x2")
+    leaves = max(1, int(leaves))
     if eager_top is None:
-        eager_top = default_eager_top(precision, len(gids))
+        # (multi-leaf mode: the waiting rollouts bring the rows; two children per expansion -- what 192+ games per rank run with --
+        # from any share: tools/leaves_cap_sweep.py, 64 games 0.137 -> 0.129 s, 128 games 0.244 -> 0.235)
+        eager_top = 2 if (leaves > 1 and precision == "f32") else default_eager_top(precision, len(gids))
     if n_pools is None:
         # two pools: the host advances one while the GPU evaluates the other's batch.  (Rounds 1-2, every child evaluated: three
         # pools paid off for f16x2 from ~200 games per rank; with the best-prior children only, batches are 5x smaller and
@@ -650,7 +653,6 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
     n_pools = max(1, min(n_pools, len(gids))) if gids else 0
     biggest_pool = max(pool_sizes) if pool_sizes else -(-len(gids) // max(1, n_pools))
     small = small_shard_defaults(precision, eager_top, biggest_pool)
-    leaves = max(1, int(leaves))
     if leaves > 1:
         small, speculate = (0, 0), 0              # (the mode brings its own rows: no evaluation ahead, batches held to whole rounds)
     if speculate is None:
@@ -678,8 +680,10 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         n_cu = getattr(getattr(evaluator, "engine", None), "n_cu", 256)
         per_round, biggest = 3 * n_cu, max((len(part) for part in parts), default=0)     # (a rank may have no game at all)
         if leaves > 1 and precision == "f32" and eager_top:
-            # ~(1 + eager_top) tasks per waiting rollout: whole rounds of 3-board workgroups nearest to what the pool asks for
-            task_cap = per_round * max(1, round((1.0 + eager_top) * leaves * biggest / per_round)) - 4
+            # measured (tools/leaves_cap_sweep.py): a pool's multi-leaf requests come to ~4-6 tasks per game and step; held to whole
+            # rounds of one-board workgroups (252 tasks: 296 us) a 32-game pool's steps cost 0.123 s per 64-game share against 0.128
+            # uncapped, a 64-game pool's 0.216-0.228 per 128 games against 0.235
+            task_cap = n_cu * max(1, round(4.0 * biggest / n_cu)) - 4
         elif precision == "f32" and 0 < eager_top <= 2:
             # ~2 tasks per game and step: whole rounds of 1-, 2- or 3-board workgroups (256 / 512 / 768 tasks on 256 CUs)
             task_cap = n_cu * max(1, round(2.0 * biggest / n_cu)) - 4
