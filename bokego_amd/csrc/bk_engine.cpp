@@ -185,6 +185,7 @@ struct Slot {  // one in-flight host-buffer request
     char* h_out_dev = nullptr;
     bool direct = false;    // this request's outputs were written to h_out by the kernel (no D2H copy was enqueued)
     int dtype = 0;
+    const void* d_feats = nullptr;   // what the request's leaf kernel read (d_in, or the records in h_in_dev: fused encoding): its redo reads the same
     hipEvent_t in_ready = nullptr;   // H2D of this request finished (copy-in stream)
     hipEvent_t head_ready = nullptr; // ... of its first part (large requests are launched in two parts)
     hipEvent_t computed = nullptr;   // kernel of this request finished (compute stream)
@@ -232,7 +233,7 @@ struct bk_engine {
     unsigned int redo_seen[BK_DEV_FLAGS] = {};
     // switches (bk_engine_set_option; defaults from the environment, read once at create)
     bk_plan_opts plan;                   // force_nb, no_split, coop, coop3
-    int no_direct = 0, no_head_part = 0, encode_overlap = 0, copy_threads = 6;
+    int no_direct = 0, no_head_part = 0, encode_overlap = 0, copy_threads = 6, no_fuse_encode = 0;
 #ifdef BK_TEST_HOOKS
     // test builds only (make hooks): the n-th HIP call of every ticket submission (fault_submit), or of anything from now on
     // (bk_debug_fail_nth_hip_call), reports a failure instead of being made; coop_fault: a cooperative peer deserts
@@ -734,6 +735,7 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->no_direct = env_str("BK_NO_DIRECT") != nullptr;
     e->no_head_part = env_str("BK_NO_HEAD_PART") != nullptr;
     e->encode_overlap = env_str("BK_ENCODE_OVERLAP") != nullptr;
+    e->no_fuse_encode = env_str("BK_NO_FUSE_ENCODE") != nullptr;
     e->copy_threads = env_int("BK_COPY_THREADS", 6);
     (void)roctx();                                           // BK_ROCTX: the marker library is looked up now, not by the first request
     int rc = BK_OK;
@@ -891,7 +893,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
                     float* probs, float* values) {
     int rc = BK_OK;
     const size_t bytes = (size_t)B * (src_kind == kSrcPositions ? (size_t)BK_POS_BYTES : src_kind == BK_FEATS_U8 ? 2187 : 2187 * 4);
-    const int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
+    int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
     // small requests (the single-tree genmove regime) have nothing to overlap: everything goes on the compute
     // stream and the two cross-stream event hops are saved; large ones use the three-stream chain
     const bool chained = B > 256;
@@ -952,7 +954,16 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
         // kernel its workgroups wait for CUs, so it "ran" 110-370 us per call (6-8 % of the summed kernel time of a
         // self-play generation, profiles/r02_selfplay_*), for a kernel that needs 13 us.  Option encode_overlap = 1 restores that.
         const bool enc_overlap = e->encode_overlap != 0;
-        if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
+        // Small direct requests of position records: NO encoder launch at all -- the leaf kernel computes the planes from the records
+        // while it stages them (bk_kernels.hip, stage_positions): one kernel instead of two on the critical path of a one-tree
+        // search's request, ~8 us of a ~130-us round trip.  Larger requests keep the encoder kernel (13 us per 4,096 records at full
+        // occupancy beats every workgroup encoding for itself).  Option no_fuse_encode = 1 restores the two kernels; same planes, same bits.
+        const void* d_feats = s->d_in;
+        if (direct && src_kind == kSrcPositions && !e->no_fuse_encode) {
+            d_feats = s->h_in_dev;
+            dtype = BK_FEATS_POS_;
+            bump(e->st.positions_encoded, (uint64_t)B);
+        } else if (src_kind == kSrcPositions && (enc_overlap || !chained)) {
             HIP_TRY(e, bk_launch_encode(direct ? s->h_in_dev : s->d_pos, B, static_cast<uint8_t*>(s->d_in), sin));
             bump(e->st.positions_encoded, (uint64_t)B);
         }
@@ -990,7 +1001,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
             rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
                          false, kHeadRows, B);
         } else {
-            rc = enqueue(e, s->d_in, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
+            rc = enqueue(e, d_feats, dtype, B, n_policy, want, o_logits, o_probs, o_values, e->stream, e->precision, d_flag, 1, false,
                          /*allow_coop=*/true);
         }
         if (rc) return rc;
@@ -1006,6 +1017,7 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
     s->B = B;
     s->n_policy = n_policy;
     s->dtype = dtype;
+    s->d_feats = dtype == BK_FEATS_POS_ ? s->h_in_dev : s->d_in;
     s->want = want;
     s->logits = logits;
     s->probs = probs;
@@ -1075,7 +1087,7 @@ int bk_wait(bk_engine* e, int64_t ticket) {
                 bump(e->st.f16_overflow_fallbacks);
             }
             s.flag_dirty = true;
-            int rc = enqueue(e, s.d_in, s.dtype, s.B, s.n_policy, s.want, reinterpret_cast<float*>(s.d_out + s.off_logits),
+            int rc = enqueue(e, s.d_feats, s.dtype, s.B, s.n_policy, s.want, reinterpret_cast<float*>(s.d_out + s.off_logits),
                              reinterpret_cast<float*>(s.d_out + s.off_probs), reinterpret_cast<float*>(s.d_out + s.off_values),
                              e->stream, BK_PRECISION_F32, nullptr);
             if (rc) return rc;
@@ -1242,6 +1254,7 @@ int* option_field(bk_engine* e, const std::string& n) {
     if (n == "no_direct") return &e->no_direct;
     if (n == "no_head_part") return &e->no_head_part;
     if (n == "encode_overlap") return &e->encode_overlap;
+    if (n == "no_fuse_encode") return &e->no_fuse_encode;
     if (n == "copy_threads") return &e->copy_threads;
 #ifdef BK_TEST_HOOKS
     if (n == "coop_fault") return &e->coop_fault;
@@ -1265,7 +1278,7 @@ int bk_engine_set_option(bk_engine* e, const char* name, int value) {
     else if (n == "coop3") ok = one_of({-1, 0, 2, 4, 8});
     else if (n == "copy_threads") ok = value >= 0 && value <= 64;
     else if (n == "coop_fault" || n == "fault_submit") ok = value >= 0;   // (test builds: fault_submit = the HIP call of a submission that fails)
-    else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap
+    else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap, no_fuse_encode
     if (!ok) return fail(e, BK_ERR_ARG, std::string("engine option '") + name + "': value " + std::to_string(value) + " out of range");
     for (const auto& sl : e->slots)
         if (sl.busy && (n == "coop" || n == "coop3" || n == "force_nb" || n == "no_split"))

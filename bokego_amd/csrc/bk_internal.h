@@ -23,6 +23,7 @@
 
 #define BK_FEATS_F32_ 0
 #define BK_FEATS_U8_ 1
+#define BK_FEATS_POS_ 2   // `feats` = 192-byte position records: the leaf kernel computes the planes itself (small requests; bk_encode_dev.h)
 
 struct bk_net_params {
     const float* wfrag;    // BK_WFRAG_FLOATS (+pad), BatchNorm folded, fragment order of conv_layer (bk_kernels.hip);
@@ -43,7 +44,7 @@ struct bk_net_params {
 
 struct bk_eval_args {
     bk_net_params net[2];  // [0] policy, [1] value
-    const void* feats;     // [B][27][9][9] f32 or u8 (device)
+    const void* feats;     // [B][27][9][9] f32 or u8 (device), or [B] position records of 192 bytes (BK_FEATS_POS_)
     int feats_dtype;
     int B_policy;          // PolicyNet runs on positions [0, B_policy)   (0: not at all)
     int B_value;           // ValueNet  runs on positions [0, B_value)

@@ -38,6 +38,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "bk_encode_dev.h"
 #include "bk_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -524,9 +525,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 // every thread fetches its <= ceil(NB*2187/THREADS) elements first (all loads in flight: the loop used to pay one
 // global-memory latency per element), then scatters them; non-temporal: the planes are read once and must not
 // evict weight lines from L2.  The caller's __syncthreads() follows.
+// ---- the same from POSITION RECORDS (a.feats_dtype == BK_FEATS_POS_: small requests of the ticket path): the feature encoder's body
+// (bk_encode_dev.h: bitboards by ballots, chains by flood fill in registers, per-point mask algebra) runs on the workgroup's first 256
+// threads -- one thread per board point of up to three boards -- and every thread puts its point's 27 plane values straight into the
+// layer-0 layout.  The planes never exist in memory, and the request is one kernel instead of two: the encoder launch and the dependent
+// dispatch behind it (~8 us of a ~130-us round trip of the one-tree search) are gone.  In the cooperative forms every slice encodes
+// its board(s) for itself.  The encoder's 4 KB of LDS records sit in the activation region, behind the layer-0 input.
+template <int NB, int THREADS>
+__device__ __forceinline__ void stage_positions(const bk_eval_args& a, char* actb, int b0, int nb, int tid) {
+    using G = Geo<NB>;
+    static_assert(THREADS >= 256, "the encoder's mapping: one thread per board point of up to three boards");
+    constexpr int SCRATCH = (G::L0_BYTES + 15) & ~15;
+    static_assert(SCRATCH + (int)sizeof(bk_enc::EncLds) <= G::L3_BYTES, "the encoder's records live behind the layer-0 input");
+    bk_enc::EncLds& S = *reinterpret_cast<bk_enc::EncLds*>(actb + SCRATCH);
+    // zero the layer-0 region (halo!); the barriers inside encode_points order it before the stores below
+    for (int i = tid; i < G::L0_BYTES / 16; i += THREADS) reinterpret_cast<f32x4*>(actb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned char v[27];
+    bool live;
+    int p, q;
+    bk_enc::encode_points(static_cast<const unsigned char*>(a.feats) + (size_t)b0 * BK_POS_BYTES, nb, tid, S, v, live, p, q);
+    if (live) {
+        const int y = q / 9, x = q - 9 * y;
+        char* rec = actb + G::addr0(p, y, x);
+#pragma unroll
+        for (int c = 0; c < 27; ++c) *reinterpret_cast<float*>(rec + in_slot(c) * 4) = (float)v[c];
+    }
+}
+
 template <int NB, int THREADS>
 __device__ __forceinline__ void stage_input(const bk_eval_args& a, char* actb, int b0, int nb, int tid) {
     using G = Geo<NB>;
+    if (a.feats_dtype == BK_FEATS_POS_) {               // (uniform over the launch)
+        stage_positions<NB, THREADS>(a, actb, b0, nb, tid);
+        return;
+    }
     constexpr int PER = (NB * 2187 + THREADS - 1) / THREADS;
     const int n = nb * 2187;
     // every load is issued unconditionally (from a clamped, always valid index) and selected afterwards: a load behind a per-lane

@@ -93,6 +93,26 @@ def test_cooperative_form_falls_back_when_a_peer_never_arrives():
     eng.close()
 
 
+def test_a_failed_cooperative_request_of_position_records_is_redone_from_the_records():
+    """Round 6: a small request of position records has no planes in memory (the leaf kernel computes them while staging); when a
+    peer deserts, bk_wait's redo with one CU per board reads the same records again: the usual bits."""
+    from bokego_amd.workload import make_batch
+    x8, recs = make_batch(64, seed_base=8_000, dtype=np.uint8, with_records=True)
+    pw, vw = load_bkw(os.path.join(GOLDEN, "policy_19.bkw")), load_bkw(os.path.join(GOLDEN, "value_synth.bkw"))
+    eng = _hooked(pw, vw, max_batch=64)
+    ref = eng.eval(x8[:48], logits=True, probs=True, value=True, n_policy=5)
+    eng.set_option("coop_fault", 1)
+    bad = eng.wait(eng.submit_positions(recs[:48], logits=True, probs=True, value=True, n_policy=5))
+    eng.set_option("coop_fault", 0)
+    st = eng.stats()
+    assert st["coop_fallbacks"] == 1
+    good = eng.wait(eng.submit_positions(recs[:48], logits=True, probs=True, value=True, n_policy=5))
+    assert eng.stats()["coop_fallbacks"] == 1
+    for k in ref:
+        assert np.array_equal(ref[k], bad[k]) and np.array_equal(ref[k], good[k]), k
+    eng.close()
+
+
 def test_cooperative_failure_is_sticky_for_requests_queued_behind_it():
     """A is submitted with a deserting slice, B and C right behind it, all three cooperative, before
     anything is waited for.  A's peers time out and raise the engine's poison word; B and C run before the host has

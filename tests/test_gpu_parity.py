@@ -681,6 +681,42 @@ def test_small_requests_without_copies_give_the_same_bits(weights):
     eng.close()
 
 
+def test_planes_computed_inside_the_leaf_kernel_give_the_same_bits(weights):
+    """Round 6: a small request of position records is ONE kernel -- the leaf kernel computes the 27 planes from the 192-byte records
+    while it stages them (the feature encoder's device code, bk_encode_dev.h), in every launch form: 12 ... 2 CUs per board, three
+    boards on 8 / 4 CUs, whole-board workgroups of one board.  Option no_fuse_encode = 1 puts the encoder kernel back in front:
+    the same planes, so every output bit is the same -- and the same as for the reference's own planes of those positions
+    (make_batch's planes come from the host encoder, bit-exact against the reference's: tests/test_go_features.py)."""
+    from bokego_amd.engine import LeafEngine
+    from bokego_amd.workload import make_batch
+    x8, recs = make_batch(256, seed_base=93_000, dtype=np.uint8, with_records=True)
+    eng = LeafEngine(weights[0], weights[1], max_batch=512)
+    shapes = [(1, 1), (3, 3), (12, 1), (17, 17), (25, 25), (35, 35), (45, 45), (62, 1), (80, 80), (81, 0), (110, 1), (200, 7), (256, 256)]
+    run = lambda B, npol: eng.wait(eng.submit_positions(recs[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol))  # noqa: E731
+    enc0 = eng.stats()["positions_encoded"]
+    fused = {sh: run(*sh) for sh in shapes}
+    assert eng.stats()["positions_encoded"] - enc0 == sum(B for B, _ in shapes)
+    eng.set_option("no_fuse_encode", 1)
+    for sh in shapes:
+        two = run(*sh)
+        planes = eng.eval(x8[:sh[0]], logits=sh[1] > 0, probs=sh[1] > 0, value=True, n_policy=sh[1])
+        for k in two:
+            assert np.array_equal(fused[sh][k], two[k]) and np.array_equal(fused[sh][k], planes[k]), (sh, k)
+    eng.set_option("no_fuse_encode", 0)
+    with eng.options(coop=0):                       # ... and in whole-board workgroups of one, two, three boards
+        for sh in ((3, 3), (62, 1), (200, 7)):
+            got = run(*sh)
+            for k in got:
+                assert np.array_equal(fused[sh][k], got[k]), (sh, k)
+    for nb in (1, 2, 3):
+        with eng.options(force_nb=nb):
+            got = run(200, 7)
+            for k in got:
+                assert np.array_equal(fused[(200, 7)][k], got[k]), (nb, k)
+    assert eng.stats()["coop_fallbacks"] == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
 def test_weights_replaced_in_a_live_engine(precision):
     """bk_engine_set_weights (ABI 5): new weights into an engine that has already evaluated -- what an optimizer step or a

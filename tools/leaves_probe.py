@@ -21,7 +21,7 @@ if "--match-only" not in sys.argv:
     selfplay.self_play(ev, n_games=64, rollouts=50, cap=8192)
     for world, threads in ((8, 4), (4, 4), (1, 12)) if not quick else ((8, 4),):
         games = {}
-        for leaves in (1, 2, 4, 8, 16, 32):
+        for leaves in (1, 2, 4, 8, 16, 32) if "--ab" not in sys.argv else (1, 8):
             best = None
             for _ in range(3):
                 local, total = selfplay.self_play(ev, n_games=512, rollouts=400, rank=0, world=world, cap=8192, threads=threads, leaves=leaves)
