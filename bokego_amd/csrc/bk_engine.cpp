@@ -234,6 +234,11 @@ struct bk_engine {
     // switches (bk_engine_set_option; defaults from the environment, read once at create)
     bk_plan_opts plan;                   // force_nb, no_split, coop, coop3
     int no_direct = 0, no_head_part = 0, encode_overlap = 0, copy_threads = 6, no_fuse_encode = 0;
+    // requests of position records up to this many rows take the copy-free one-kernel path (option "direct_rows"): 256 until round 6; a
+    // 512-game generation's steps (~340 rows) without their H2D copy, encoder kernel and two event hops: 0.822 -> 0.789 s
+    // (tools/direct_rows_probe.py; 512 / 1024 / 4096 measure the same); larger requests keep the three-stream chain, which overlaps
+    // their copies with other tickets' kernels
+    int direct_rows = 1024;
 #ifdef BK_TEST_HOOKS
     // test builds only (make hooks): the n-th HIP call of every ticket submission (fault_submit), or of anything from now on
     // (bk_debug_fail_nth_hip_call), reports a failure instead of being made; coop_fault: a cooperative peer deserts
@@ -736,6 +741,7 @@ int bk_engine_create(const bk_policy_weights* policy, const bk_value_weights* va
     e->no_head_part = env_str("BK_NO_HEAD_PART") != nullptr;
     e->encode_overlap = env_str("BK_ENCODE_OVERLAP") != nullptr;
     e->no_fuse_encode = env_str("BK_NO_FUSE_ENCODE") != nullptr;
+    e->direct_rows = env_int("BK_DIRECT_ROWS", 1024);
     e->copy_threads = env_int("BK_COPY_THREADS", 6);
     (void)roctx();                                           // BK_ROCTX: the marker library is looked up now, not by the first request
     int rc = BK_OK;
@@ -894,9 +900,9 @@ int64_t submit_body(bk_engine* e, Slot* s, const void* src, int src_kind, int B,
     int rc = BK_OK;
     const size_t bytes = (size_t)B * (src_kind == kSrcPositions ? (size_t)BK_POS_BYTES : src_kind == BK_FEATS_U8 ? 2187 : 2187 * 4);
     int dtype = src_kind == BK_FEATS_F32 ? BK_FEATS_F32 : BK_FEATS_U8;  // what the leaf kernel reads from d_in
-    // small requests (the single-tree genmove regime) have nothing to overlap: everything goes on the compute
-    // stream and the two cross-stream event hops are saved; large ones use the three-stream chain
-    const bool chained = B > 256;
+    // small requests (the single-tree genmove regime; for position records: up to direct_rows) have nothing to overlap: everything
+    // goes on the compute stream and the two cross-stream event hops are saved; large ones use the three-stream chain
+    const bool chained = B > (src_kind == kSrcPositions ? e->direct_rows : 256);
     hipStream_t sin = chained ? e->s_in : e->stream, sout = chained ? e->s_out : e->stream;
     // Small fp32 requests (the one-tree genmove regime: a 62-board expansion batch is a 108 us kernel) go "direct": no H2D
     // copy of position records -- the encoder reads them from the pinned slot over PCIe (12 KB) -- and no D2H copy -- the
@@ -1255,6 +1261,7 @@ int* option_field(bk_engine* e, const std::string& n) {
     if (n == "no_head_part") return &e->no_head_part;
     if (n == "encode_overlap") return &e->encode_overlap;
     if (n == "no_fuse_encode") return &e->no_fuse_encode;
+    if (n == "direct_rows") return &e->direct_rows;
     if (n == "copy_threads") return &e->copy_threads;
 #ifdef BK_TEST_HOOKS
     if (n == "coop_fault") return &e->coop_fault;
@@ -1277,6 +1284,7 @@ int bk_engine_set_option(bk_engine* e, const char* name, int value) {
     else if (n == "coop") ok = one_of({-1, 0, 2, 3, 4, 6, 8, 12});
     else if (n == "coop3") ok = one_of({-1, 0, 2, 4, 8});
     else if (n == "copy_threads") ok = value >= 0 && value <= 64;
+    else if (n == "direct_rows") ok = value >= 0 && value <= (1 << 20);
     else if (n == "coop_fault" || n == "fault_submit") ok = value >= 0;   // (test builds: fault_submit = the HIP call of a submission that fails)
     else ok = value == 0 || value == 1;              // no_split, no_direct, no_head_part, encode_overlap, no_fuse_encode
     if (!ok) return fail(e, BK_ERR_ARG, std::string("engine option '") + name + "': value " + std::to_string(value) + " out of range");

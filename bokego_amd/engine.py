@@ -266,7 +266,7 @@ class LeafEngine:
     # -- misc ---------------------------------------------------------------------------------
     def set_option(self, name, value):
         """A diagnostic switch of this engine (bk_engine_set_option): 'coop', 'coop3', 'force_nb', 'no_split', 'no_direct',
-        'no_head_part', 'copy_threads', 'encode_overlap', 'no_fuse_encode'.  The environment is read once, when the engine is created; a live
+        'no_head_part', 'copy_threads', 'encode_overlap', 'no_fuse_encode', 'direct_rows'.  The environment is read once, when the engine is created; a live
         engine is changed here.  Results never depend on a switch."""
         self._check(self._lib.bk_engine_set_option(self._h, name.encode(), int(value)))
 

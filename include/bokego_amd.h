@@ -215,7 +215,8 @@ int bk_engine_set_profiling(bk_engine *e, int on); /* HIP-event timing of every 
  * force each form.  Names: "force_nb" (0 | 1..3 boards per workgroup), "no_split", "coop" (-1 by task count | 0 off | 2, 3,
  * 4, 6, 8, 12 CUs per board), "coop3" (-1 | 0 | 2 | 4 | 8), "no_direct", "no_head_part", "copy_threads", "encode_overlap",
  * "no_fuse_encode" (1: small requests of position records run the encoder kernel in front of the leaf kernel again instead of
- * letting the leaf kernel compute the planes from the records while it stages them; BK_NO_FUSE_ENCODE at create).
+ * letting the leaf kernel compute the planes from the records while it stages them; BK_NO_FUSE_ENCODE at create), "direct_rows"
+ * (requests of position records up to this many rows -- default 1024 -- take the copy-free one-kernel path; BK_DIRECT_ROWS).
  * Unknown name or a value the switch does not know (coop = 5, copy_threads < 0): BK_ERR_ARG, nothing changed.  Like every call
  * on an engine handle it belongs to the one thread that submits (the handle is single-consumer); the planner's switches
  * ("force_nb", "no_split", "coop", "coop3") are refused while tickets are in flight -- a request's redo after a failed cooperative
