@@ -137,7 +137,7 @@ def test_host_library_exports_go_and_tree_headers():
             assert hasattr(lib, f)
     assert lib.bk_go_abi_version() == 6
     assert C.sizeof(selfplay.GameStats) == 81 * 8 + 24 and C.sizeof(selfplay.EvaluatorStruct) == 24 and C.sizeof(selfplay.RunInfo) == 40
-    assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 96 and C.sizeof(selfplay.NodeInfo) == 24 and C.sizeof(selfplay.GameInfo) == 56
+    assert C.sizeof(go.Pos) == 192 and C.sizeof(selfplay.SearchParams) == 104 and C.sizeof(selfplay.NodeInfo) == 24 and C.sizeof(selfplay.GameInfo) == 56
 
 
 def test_lds_edge_tables_match_generator():
