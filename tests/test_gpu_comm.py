@@ -17,7 +17,30 @@ def test_native_allreduce_world1(tmp_path):
     assert np.array_equal(c.allreduce_sum(np.zeros(0)), np.zeros(0))
     with pytest.raises(RuntimeError):
         c.allreduce_sum(np.zeros(5000))
+    # comm ABI 2 (round 6): the barrier in front of the timed all-reduce, and what the first multi-GPU line says about its fabric
+    c.barrier()
+    assert c.rccl_version() > 20000 and len(c.device_pci()) >= 12 and c.device_pci().count(":") == 2
     c.close()
+
+
+def test_bench_line_over_rccl_at_one_rank():
+    """bench.py with torch.distributed's nccl backend (= RCCL) forced on at one rank: the same code the driver's N > 1 runs take --
+    process group on the device, barrier, the statistics' all-reduce timed apart from the wait, RCCL's version and the rank's card
+    in the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, BK_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--sustain", "0", "--no-cpu-baseline",
+                          "--no-live-pmc", "--selfplay-games", "32", "--no-f16x2"], capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["collective_backend"] == "nccl" and d["collective_ranks_seen"] == 1
+    assert d["rccl_version"] and d["rccl_version"][0].isdigit() and d["rank_devices"][0]["pci"].count(":") == 2
+    f = d["selfplay"]["f32"]
+    assert 0 < f["stats_allreduce_ms"] < 50 and len(f["allreduce_wait_ms_per_rank"]) == 1 and f["games"] == 32
 
 
 def test_native_broadcast_world1_and_python_wrapper(tmp_path):
