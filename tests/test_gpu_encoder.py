@@ -108,3 +108,27 @@ def test_self_play_same_games_with_gpu_and_host_encoding(eng):
         res.append((local["games"], total))
     assert res[0][0] == res[1][0]
     assert res[0][1] == res[1][1]
+
+
+def test_records_through_the_one_kernel_path_give_the_references_outputs(eng):
+    """Round 6: requests of up to 1,024 position records never have planes in memory -- the leaf kernel computes them from the records
+    while it stages.  The 536 golden positions, replayed move by move so that the liberty cache has the reference's history, sent as
+    RECORDS in requests of every launch form's size: logits / probs / values are the reference's recorded outputs (tests/golden/nets.npz)
+    within north_star's tolerance, and bit for bit what the same engine gives for the reference's recorded PLANES."""
+    n = np.load(os.path.join(GOLDEN, "nets.npz"))
+    finc = np.load(os.path.join(GOLDEN, "features.npz"))["incremental"].astype(np.uint8)
+    recs, idx, _ = _golden_records()
+    order = np.argsort(idx)
+    recs = recs[order]                                   # golden order: recs[i] is golden position i
+    lo = 0
+    for B in (1, 2, 5, 12, 17, 25, 35, 45, 60, 80, 110, 144):
+        r = recs[lo:lo + B]
+        got = eng.wait(eng.submit_positions(r, logits=True, probs=True, value=True))
+        assert np.abs(got["logits"] - n["logits_b1"][lo:lo + B]).max() < 1e-4
+        assert np.abs(got["probs"] - n["probs_b1"][lo:lo + B]).max() < 1e-5
+        assert np.abs(got["value"] - n["values_b1"][lo:lo + B]).max() < 1e-4
+        ref = eng.eval(finc[lo:lo + B], logits=True, probs=True, value=True)
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), (B, k)
+        lo += B
+    assert lo == 536
