@@ -21,6 +21,8 @@
 //     same kernel.
 // HBM traffic is therefore the compulsory 8,748 B in + 652 B out per position (+ weights, L2 resident).  BatchNorm (eval
 // mode) is folded into the weights on the host in fp64.
+//   * a small request of position records (192 B each) has no planes at all: the kernel computes them from the records while it
+//     stages (stage_positions: the feature encoder's device code, bk_encode_dev.h) -- one launch per request instead of two.
 // Batches of at most 128 (net, board) tasks take the cooperative form further down instead: 2 .. 12 workgroups on as
 // many CUs share one board, each computing a slice of every layer and exchanging slices through L2 (same bits); requests
 // between the whole-board forms' ranges (129..192 and 257..384 tasks) run as groups of THREE boards shared by 4 resp. 2 CUs.
