@@ -1370,9 +1370,11 @@ int bk_coop_slices(int tasks, int n_cu, const bk_plan_opts& o) {
     //   (.. 33);   4: 111 .. 112 (.. 64);   3 (point ranges): 146 (.. 80);   2: 190 (.. 128)
     // blocks are dealt to the 8 XCDs in turn and task t sits on XCD t % 8: what has to fit is ceil(tasks / 8) groups on the
     // n_cu / 8 CUs of one XCD (85 tasks x 3 slices = 255 workgroups, but 33 of them on each of five XCDs: 239 us)
+    // round 6 (tools/coop_forced_probe.py): with the one-tile waves' reads up front the 12-CU form also wins where TWO boards share an
+    // XCD -- 9..16 tasks 67 us against the 8-CU form's 80 (at 17 tasks and beyond, three boards per XCD, it would put two workgroups
+    // on a CU: 84 us)
     const int per_xcd = (tasks + 7) / 8, cus = n_cu / 8;
-    if (per_xcd == 1 && 12 <= cus) return 12;
-    for (int sl : {8, 6, 4, 3, 2})
+    for (int sl : {12, 8, 6, 4, 3, 2})
         if (per_xcd * sl <= cus) return sl;
     return 0;
 }

@@ -192,8 +192,9 @@ def test_launch_planner_choices(lib, monkeypatch):
         monkeypatch.setenv(v, "0")
     nb = ctypes.c_int(0)
     q = lambda npol, nval, prec=0, n_cu=256: lib.bk_plan_query(npol, nval, n_cu, prec, ctypes.byref(nb))  # noqa: E731
-    assert [q(1, 1), q(1, 7), q(1, 8), q(1, 31), q(1, 32), q(1, 39), q(1, 40), q(1, 63), q(1, 64), q(1, 79), q(1, 80), q(0, 128),
-            q(0, 0)] == [12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 108, 2, 0]
+    # (12 CUs per board while at most two boards share an XCD -- up to 16 tasks, round 6 -- then 8, 6, 4, 3, 2)
+    assert [q(1, 1), q(1, 7), q(1, 8), q(1, 15), q(1, 16), q(1, 31), q(1, 32), q(1, 39), q(1, 40), q(1, 63), q(1, 64), q(1, 79), q(1, 80),
+            q(0, 128), q(0, 0)] == [12, 12, 12, 12, 8, 8, 6, 6, 4, 4, 3, 3, 108, 2, 0]
     # 81..96 tasks in at most 32 groups of three boards of one net: three boards on EIGHT CUs (code 108; round 5: 140 us against
     # the 2-CUs-per-board form's 174); one group too many, or one task, and the 2-CUs-per-board form runs
     assert [q(0, 81), q(3, 93), q(0, 96), q(6, 90), q(1, 95), q(4, 92), q(0, 97), q(1, 79)] == [108, 108, 108, 108, 2, 2, 2, 3]

@@ -66,7 +66,7 @@ def test_batched_vs_reference_goldens(engine, gold, B):
 
 # (positions, the launch form the fp32 planner picks for B policy + B value tasks on 256 CUs): every cooperative form and the
 # whole-board forms between them -- 12 / 8 / 6 / 4 / 3 / 2 CUs per board, three boards on 8 / 4 / 2 CUs (108 / 104 / 102), 0 = whole boards
-PLANNER_CASES = [(4, 12), (12, 8), (17, 6), (25, 4), (35, 3), (45, 108), (60, 2), (80, 104), (110, 0), (150, 102), (200, 0)]
+PLANNER_CASES = [(4, 12), (8, 12), (12, 8), (17, 6), (25, 4), (35, 3), (45, 108), (60, 2), (80, 104), (110, 0), (150, 102), (200, 0)]
 
 
 @pytest.mark.parametrize("B,form", PLANNER_CASES)
