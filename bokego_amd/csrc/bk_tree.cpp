@@ -621,9 +621,9 @@ struct Game {
     // rollouts up in the order they were made.  A rollout whose leaf value is known is backed up at once, unless it ends on a node
     // whose expansion still waits for its policy row (kids without priors: nothing can be selected below it, and backing it up at
     // once would send the step's remaining rollouts down the same path): that one waits too, as in the one-leaf search.
-    static void virtual_loss(TNode& n, int sign) {
+    void virtual_loss(TNode& n, int sign) const {
         n.N += sign;
-        n.V += (double)sign;
+        if (!prm.leaves_visit_only) n.V += (double)sign;     // (visit only: the waiting rollout counts as a visit, not as a loss)
         n.avg = n.N > 0 ? n.V / (double)n.N : 0.0;
     }
     bool search_leaves() {  // true: a request goes out (n_pend rollouts wait for it); false: this move's rollouts are done
@@ -900,7 +900,7 @@ void bk_search_params_default(bk_search_params* p) {
     p->use_value = 1;
     p->value_weight = 1.0;
     p->leaves = 1;
-    p->reserved0 = 0;
+    p->leaves_visit_only = 0;
 }
 
 bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t* seeds, int threads) {
@@ -912,7 +912,7 @@ bk_pool* bk_pool_create(int n_games, const bk_search_params* prm, const uint64_t
     if (!q.use_value || q.simulate) q.speculate = 0;             // (a playout's nodes must stay the newest ones of the tree)
     if (q.leaves < 1 || !q.use_value || q.simulate || (q.branch_num > 0 && q.branch_num < 81)) q.leaves = 1;   // (bk_search_params.leaves)
     if (q.leaves > 1) q.speculate = 0;
-    q.reserved0 = 0;
+    q.leaves_visit_only = q.leaves_visit_only != 0;
     for (int i = 0; i < n_games; ++i) p->games.emplace_back(q, seeds[i]);
     p->threads = threads > 0 ? threads : 1;
     return p;
@@ -1843,7 +1843,7 @@ bool restore_game(Game& dst, const uint8_t* buf, size_t len) {
             !in(q.sample_plies, 0, 1 << 20) || !in(q.max_turns, 0, 100000) || !in(q.eager, 0, 1) || !fin(q.komi, -1000.0, 1000.0) ||
             !in(q.record_visits, 0, 1) || !in(q.prune, 0, 1) || !in(q.speculate, 0, 1 << 30) || !in(q.speculate_rows, 0, 1 << 30) ||
             !in(q.request_tasks, 0, 1 << 30) || !in(q.eager_top, 0, 81) || !in(q.branch_num, 0, 81) || !in(q.simulate, 0, 1) ||
-            !in(q.use_value, 0, 1) || !fin(q.value_weight, 0.0, 1.0) || !in(q.leaves, 1, 64) || q.reserved0 != 0)
+            !in(q.use_value, 0, 1) || !fin(q.value_weight, 0.0, 1.0) || !in(q.leaves, 1, 64) || !in(q.leaves_visit_only, 0, 1))
             return false;
         if (q.leaves > 1 && (q.simulate || !q.use_value || (q.branch_num > 0 && q.branch_num < 81) || q.speculate)) return false;   // (bk_pool_create's rule)
         for (int v : q.request_steps)

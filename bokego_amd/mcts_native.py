@@ -175,6 +175,7 @@ class NativeMCTS:
         # OPT-IN, not the reference's search: `leaves` > 1 rollouts of a step wait for their values together under virtual loss
         # (bk_search_params.leaves).  Default 1 = the reference's sequential search, rollout for rollout.
         prm.leaves = max(1, int(kwargs.get("leaves", 1)))
+        prm.leaves_visit_only = int(bool(kwargs.get("leaves_visit_only", 0)))
         if prm.leaves > 1:
             prm.speculate, prm.request_tasks = 0, 0
             prm.request_steps[0] = prm.request_steps[1] = prm.request_steps[2] = 0

@@ -33,7 +33,7 @@ class SearchParams(ctypes.Structure):
                 ("speculate_rows", ctypes.c_int32), ("request_tasks", ctypes.c_int32), ("eager_top", ctypes.c_int32),
                 ("request_steps", ctypes.c_int32 * 3), ("branch_num", ctypes.c_int32),
                 ("simulate", ctypes.c_int32), ("use_value", ctypes.c_int32), ("value_weight", ctypes.c_double),
-                ("leaves", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("leaves", ctypes.c_int32), ("leaves_visit_only", ctypes.c_int32)]
 
 
 class NodeInfo(ctypes.Structure):
@@ -623,7 +623,7 @@ def shard_game_ids(n_games, rank, world):
 def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=20260, noise_weight=0.25,
               sample_plies=8, expand_thresh=100, max_turns=80, cap=4096, threads=None, n_pools=None,
               reduce_device=None, progress=None, prune=1, record_visits=0, native_comm=None, gids=None, eager_top=None, task_cap=None,
-              dedup=None, native_loop=None, pool_sizes=None, speculate=None, speculate_rows=8, leaves=1):
+              dedup=None, native_loop=None, pool_sizes=None, speculate=None, speculate_rows=8, leaves=1, leaves_visit_only=0):
     """Play this rank's share of a generation; returns (local result dict, reduced stats dict).
     gids: play exactly these game ids instead of the shard `gid % world == rank` -- a game is a pure function of
     `seed_base + gid` and the networks, so the shard of a rank that died can be re-played anywhere (by a survivor, or by
@@ -659,7 +659,8 @@ def self_play(evaluator, n_games=512, rollouts=400, rank=0, world=1, seed_base=2
         speculate = small[0]
     prm = search_params(rollouts=rollouts, expand_thresh=expand_thresh, noise_weight=noise_weight,
                         sample_plies=sample_plies, max_turns=max_turns, prune=prune, record_visits=record_visits,
-                        eager_top=eager_top, speculate=speculate, speculate_rows=speculate_rows, leaves=leaves)
+                        eager_top=eager_top, speculate=speculate, speculate_rows=speculate_rows, leaves=leaves,
+                        leaves_visit_only=int(bool(leaves_visit_only)))
     if pool_sizes is not None:
         pool_sizes = [int(k) for k in pool_sizes if int(k) > 0]
         if sum(pool_sizes) != len(gids):

@@ -695,8 +695,8 @@ def test_multi_leaf_mode_is_off_by_default_and_conserves_every_rollout():
     the root has n more visits, its children share them all, every node's |V| <= N, and a node's visits are its own rollouts-as-leaf
     plus its children's (the same accounting identities the one-leaf search obeys)."""
     f = FakeNets()
-    for leaves in (1, 2, 4, 8):
-        t = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12, leaves=leaves)
+    for leaves, visit_only in ((1, 0), (2, 0), (4, 0), (8, 0), (4, 1), (8, 1)):     # (visit_only: the milder kind of virtual loss)
+        t = NativeMCTS(Position(), _Wrap(f.policy), _Wrap(f.value, True), expand_thresh=12, leaves=leaves, leaves_visit_only=visit_only)
         done = 0
         for n in (150, 7, 300):
             t.rollout(n)
@@ -732,8 +732,11 @@ def test_multi_leaf_games_are_a_pure_function_of_their_seeds():
         local, total = selfplay.self_play(ev, leaves=leaves, **{**kw, **extra})
         return local, total
 
+    vo, _ = run(4, n_pools=1, threads=1, leaves_visit_only=1)       # the milder kind of virtual loss: its own games, as pure a function
+    vo2, _ = run(4, n_pools=3, threads=2, leaves_visit_only=1)
+    assert vo["games"] == vo2["games"] and vo["visits"] == vo2["visits"]
     base, tot = run(4, n_pools=1, threads=1)
-    assert base["leaves"] == 4
+    assert base["leaves"] == 4 and base["games"] != vo["games"]
     for extra in (dict(n_pools=2, threads=3), dict(n_pools=3, threads=2, native_loop=False), dict(n_pools=2, threads=2, dedup=True, task_cap=30)):
         local, total = run(4, **extra)
         assert local["games"] == base["games"] and local["visits"] == base["visits"], extra
