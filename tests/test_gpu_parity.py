@@ -715,6 +715,20 @@ def test_planes_computed_inside_the_leaf_kernel_give_the_same_bits(weights):
                 assert np.array_equal(fused[(200, 7)][k], got[k]), (nb, k)
     assert eng.stats()["coop_fallbacks"] == 0
     eng.close()
+    # the copy-free one-kernel path reaches up to direct_rows = 1,024 records (a 512-game generation's steps); beyond it the three-stream
+    # chain with the encoder kernel: the same bits on either side of the limit and with the limit moved
+    xb, rb = make_batch(1100, seed_base=94_000, dtype=np.uint8, with_records=True)
+    big = LeafEngine(weights[0], weights[1], max_batch=2048)
+    want = big.eval(xb, logits=True, probs=True, value=True)
+    for B, npol in ((1000, 1000), (1024, 40), (1025, 40), (1100, 0)):
+        got = big.wait(big.submit_positions(rb[:B], logits=npol > 0, probs=npol > 0, value=True, n_policy=npol))
+        assert np.array_equal(got["value"], want["value"][:B])
+        if npol:
+            assert np.array_equal(got["logits"], want["logits"][:npol]) and np.array_equal(got["probs"], want["probs"][:npol])
+    big.set_option("direct_rows", 0)
+    got = big.wait(big.submit_positions(rb[:300], logits=True, probs=True, value=True, n_policy=300))
+    assert np.array_equal(got["logits"], want["logits"][:300]) and np.array_equal(got["value"], want["value"][:300])
+    big.close()
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
